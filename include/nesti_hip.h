@@ -1,0 +1,168 @@
+/*
+ * nesti_hip.h -- C-ABI of libnesti_hip.so: the MI355X (gfx950) implementation of
+ * Nesti-Net's per-point inference hot path.
+ *
+ * The reference (sitzikbs/Nesti-Net, Python 2.7 + TF 1.12) has no FFI or operator
+ * registry; its seams are Python call sites.  Each entry point below names the
+ * reference interface it replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every `*_dev` pointer is a caller-owned DEVICE pointer (e.g. torch tensor
+ *     .data_ptr()); the library never allocates outputs or frees inputs;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     launches are asynchronous on it and no call synchronises the device
+ *     unless stated;
+ *   - return value 0 = ok, non-zero = error; nesti_last_error() returns a
+ *     thread-local message for the last failing call on this thread;
+ *   - model handles are immutable after creation: concurrent forward calls on
+ *     different streams are safe provided they use different workspaces.
+ */
+#ifndef NESTI_HIP_H
+#define NESTI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NESTI_MAX_SCALES 4
+#define NESTI_MAX_EXPERTS 8
+#define NESTI_MUPS_CH 20 /* channels per scale: utils/tf_util.py:711-720 */
+
+/* element types for activations / weights */
+enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2 };
+
+/* which graph nesti_model_create builds */
+enum {
+  NESTI_ARCH_EXPERTS = 0, /* models/experts_n_est.py:40-108  (MoE, the hot path)    */
+  NESTI_ARCH_SINGLE = 1   /* models/ss_norm_est.py:35-92     (BASELINE config 0)    */
+};
+
+/* Hyper-parameters the reference reads from parameters.p / gmm.p
+ * (test_n_est_w_experts.py:46-54, :201). */
+typedef struct {
+  int arch;                                /* NESTI_ARCH_*                                      */
+  int n_scales;                            /* len(patch_radius)                                 */
+  int points_per_scale;                    /* num_point (P)                                     */
+  int grid_n;                              /* Gaussians per axis (8)                            */
+  double variance;                         /* gmm covariance (0.0156)                           */
+  int n_experts;                           /* E                                                 */
+  int expert_scale_lo[NESTI_MAX_EXPERTS];  /* min(expert_dict[i])   models/experts_n_est.py:100 */
+  int expert_scale_cnt[NESTI_MAX_EXPERTS]; /* len(expert_dict[i])   models/experts_n_est.py:101 */
+} nesti_config_t;
+
+/* One named float32 host tensor in TF variable layout
+ * (conv [kd,kh,kw,Cin,Cout] utils/tf_util.py:289; fc [In,Out] utils/tf_util.py:334). */
+typedef struct {
+  const char* name;
+  const float* data; /* host pointer; may be NULL in nesti_model_describe output */
+  int ndim;
+  int64_t dims[5];
+} nesti_tensor_t;
+
+typedef struct nesti_model nesti_model_t;
+
+const char* nesti_last_error(void);
+const char* nesti_version(void);
+
+/* Fill cfg with the trained Nesti-Net command line (train_n_est_w_experts.py:20,62). */
+void nesti_default_config(nesti_config_t* cfg);
+
+/* utils/utils.py:70-95 get_3d_grid_gmm: host arrays w[n^3], mu[n^3*3], sigma[n^3*3]
+ * (sigma = sqrt(covariances_), as fed at test_n_est_w_experts.py:146). */
+int nesti_gmm_grid(int n, double variance, float* w, float* mu, float* sigma);
+
+/* utils/tf_util.py:655-753 get_3dmfv_n_est + models/experts_n_est.py:66-76 (MuPS
+ * assembly) with the exact TF placeholder contract (models/experts_n_est.py:26-35):
+ *   points_dev [B, S*P, 3] f32, n_eff_dev [B, S] int32
+ *   out_dev    [B, R, R, R, out_cstride] of out_dtype; channel 20*s+c holds
+ *              scale s, statistic c; channels >= 20*S are written as zero.
+ * Rows whose n_eff is 0 (the zero-padded tail of the reference's last batch,
+ * test_n_est_w_experts.py:134-140) are written as zeros instead of NaN. */
+int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev,
+                       const int32_t* n_eff_dev, int B, void* out_dev, int out_dtype,
+                       int out_cstride, void* stream);
+
+/* utils/pcpnet_dataset.py:286-343 __getitem__ (center='point', use_pca=False,
+ * point_tuple=1) for M query points of one cloud, on the GPU:
+ *   cloud_dev [N,3] f32; query_idx_dev [M] int32 (NULL = 0..M-1, the 'full'
+ *   sampler utils/pcpnet_dataset.py:41-55); r_abs[S] = bbdiag*rad as double
+ *   (utils/pcpnet_dataset.py:282); query_row0 = patch row of the first query within
+ *   its shape (so the subsample below does not depend on how rows are batched).
+ * Ball membership is the fp64 test scipy's cKDTree applies (:304).  When a ball
+ * holds more than P points the P kept are those with the smallest
+ * (hash(seed, query_row0+i, scale, index), index) keys -- a uniform P-subset like :320-321
+ * but reproducible; see DESIGN.md.  Outputs (any may be NULL):
+ *   points_out_dev [M,S*P,3] f32, n_eff_out_dev [M,S] int32,
+ *   nbr_idx_out_dev [M,S*P] int32 (-1 padded), n_ball_out_dev [M,S] int32 (uncapped).
+ * grid_ws_dev / grid_ws_bytes: scratch from nesti_patches_workspace_bytes(N). */
+size_t nesti_patches_workspace_bytes(int N);
+/* Step 1 (once per cloud; replaces the cKDTree build, utils/pcpnet_dataset.py:37): bounding
+ * box, cell counts, scan and cell-ordered copy of the cloud into grid_ws_dev. */
+int nesti_patches_grid(const nesti_config_t* cfg, const float* cloud_dev, int N,
+                       const double* r_abs, void* grid_ws_dev, size_t grid_ws_bytes,
+                       void* stream);
+/* Step 2 (per batch of queries; replaces __getitem__, utils/pcpnet_dataset.py:286-343). */
+int nesti_patches_query(const nesti_config_t* cfg, const float* cloud_dev, int N,
+                        const int32_t* query_idx_dev, int M, const double* r_abs,
+                        uint64_t seed, int query_row0, float* points_out_dev,
+                        int32_t* n_eff_out_dev, int32_t* nbr_idx_out_dev,
+                        int32_t* n_ball_out_dev, const void* grid_ws_dev,
+                        size_t grid_ws_bytes, void* stream);
+/* Steps 1 + 2 in one call. */
+int nesti_patches_build(const nesti_config_t* cfg, const float* cloud_dev, int N,
+                        const int32_t* query_idx_dev, int M, const double* r_abs,
+                        uint64_t seed, int query_row0, float* points_out_dev,
+                        int32_t* n_eff_out_dev, int32_t* nbr_idx_out_dev,
+                        int32_t* n_ball_out_dev, void* grid_ws_dev, size_t grid_ws_bytes,
+                        void* stream);
+
+/* Enumerate the variables the graph for cfg expects (names follow the reference's
+ * scopes, models/experts_n_est.py:155-314).  Call with infos=NULL to get the count. */
+int nesti_model_describe(const nesti_config_t* cfg, int* n_tensors, nesti_tensor_t* infos,
+                         int max_infos);
+
+/* tf.train.Saver().restore equivalent (test_n_est_w_experts.py:98-105): takes the
+ * float32 variables, folds the inference-mode batch norm (utils/tf_util.py:491-494)
+ * into weights+bias, repacks for the MFMA kernels in `dtype` and uploads.
+ * This call allocates device memory owned by the handle and synchronises. */
+int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
+                       int n_tensors, int dtype, nesti_model_t** out);
+void nesti_model_destroy(nesti_model_t* m);
+
+/* Scratch size for forward calls of up to max_batch points. */
+size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch);
+int nesti_model_mups_cstride(const nesti_model_t* m); /* channel stride of the internal MuPS tensor */
+
+/* scale_manager_net + arg-max (models/experts_n_est.py:155-179,
+ * test_n_est_w_experts.py:150): mups_dev is [B,R^3,cstride] in the model dtype.
+ * probs_out_dev [B,E] f32 (row-major, i.e. the transpose done at :151),
+ * expert_out_dev [B] int32 (first index on ties, like np.argmax). */
+int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void* ws_dev,
+                       size_t ws_bytes, float* probs_out_dev, int32_t* expert_out_dev,
+                       void* stream);
+
+/* normal_est_net for every expert (models/experts_n_est.py:99-105, 243-291).
+ * expert_dev == NULL : evaluate all experts, normals_out_dev is [E,B,3] (what the
+ *                      reference's sess.run returns, test_n_est_w_experts.py:148);
+ * expert_dev != NULL : top-1 routing -- only expert_dev[b] is evaluated for point b
+ *                      and normals_out_dev is [B,3] (== n_est[e*,b,:], :152). */
+int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const int32_t* expert_dev,
+                          int B, void* ws_dev, size_t ws_bytes, float* normals_out_dev,
+                          void* stream);
+
+/* One sess.run([n_pred, experts_prob]) + arg-max/select
+ * (test_n_est_w_experts.py:142-152) with top-1 routing:
+ *   points_dev [B,S*P,3] f32, n_eff_dev [B,S] int32 ->
+ *   normals_out_dev [B,3] f32, expert_out_dev [B] int32, probs_out_dev [B,E] f32.
+ * For NESTI_ARCH_SINGLE only normals are produced (expert/probs may be NULL). */
+int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev,
+                  int B, void* ws_dev, size_t ws_bytes, float* normals_out_dev,
+                  int32_t* expert_out_dev, float* probs_out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NESTI_HIP_H */

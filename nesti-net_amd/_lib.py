@@ -1,0 +1,91 @@
+"""ctypes binding of ``libnesti_hip.so`` (C-ABI: include/nesti_hip.h).
+
+Fails loudly when the library is missing -- there is no CPU or eager fallback."""
+import ctypes
+import os
+
+from .config import CConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnesti_hip.so")
+
+
+class CTensor(ctypes.Structure):
+    """Mirror of ``nesti_tensor_t``."""
+    _fields_ = [("name", ctypes.c_char_p),
+                ("data", ctypes.c_void_p),
+                ("ndim", ctypes.c_int),
+                ("dims", ctypes.c_int64 * 5)]
+
+
+class NestiError(RuntimeError):
+    pass
+
+
+_vp, _i, _sz, _u64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_uint64
+_cfgp = ctypes.POINTER(CConfig)
+
+# name -> (restype, argtypes); every symbol include/nesti_hip.h declares
+SIGNATURES = {
+    "nesti_last_error": (ctypes.c_char_p, []),
+    "nesti_version": (ctypes.c_char_p, []),
+    "nesti_default_config": (None, [_cfgp]),
+    "nesti_gmm_grid": (_i, [_i, ctypes.c_double, _vp, _vp, _vp]),
+    "nesti_mups_forward": (_i, [_cfgp, _vp, _vp, _i, _vp, _i, _i, _vp]),
+    "nesti_patches_workspace_bytes": (_sz, [_i]),
+    "nesti_patches_grid": (_i, [_cfgp, _vp, _i, ctypes.POINTER(ctypes.c_double), _vp, _sz, _vp]),
+    "nesti_patches_query": (_i, [_cfgp, _vp, _i, _vp, _i, ctypes.POINTER(ctypes.c_double), _u64, _i,
+                                 _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nesti_patches_build": (_i, [_cfgp, _vp, _i, _vp, _i, ctypes.POINTER(ctypes.c_double), _u64, _i,
+                                 _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nesti_model_describe": (_i, [_cfgp, ctypes.POINTER(_i), ctypes.POINTER(CTensor), _i]),
+    "nesti_model_create": (_i, [_cfgp, ctypes.POINTER(CTensor), _i, _i, ctypes.POINTER(_vp)]),
+    "nesti_model_destroy": (None, [_vp]),
+    "nesti_workspace_bytes": (_sz, [_vp, _i]),
+    "nesti_model_mups_cstride": (_i, [_vp]),
+    "nesti_gate_forward": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
+    "nesti_experts_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
+    "nesti_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NestiError(
+            "libnesti_hip.so not found at %s -- build it first: "
+            "python -c 'import __graft_entry__ as g; g.build()' (or make -C nesti-net_amd/csrc). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().nesti_last_error()
+        raise NestiError("%s failed: %s" % (what or "libnesti_hip call", msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.ctypes.data)
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)

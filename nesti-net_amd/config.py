@@ -1,0 +1,80 @@
+"""Hyper-parameters of the hot path (the reference's ``parameters.p`` / ``gmm.p``,
+``test_n_est_w_experts.py:46-54,201``), as one dataclass."""
+import ctypes
+import json
+from dataclasses import dataclass, field
+from typing import Dict, List
+
+MAX_SCALES = 4
+MAX_EXPERTS = 8
+DTYPES = {"f32": 0, "bf16": 1, "f16": 2}
+ARCH_EXPERTS, ARCH_SINGLE = 0, 1
+
+# train_n_est_w_experts.py:62 (JSON-in-JSON there; plain dict here)
+TRAINED_EXPERT_DICT = {0: [0], 1: [0], 2: [1], 3: [1], 4: [2], 5: [2], 6: [0, 1, 2]}
+
+
+class CConfig(ctypes.Structure):
+    """Mirror of ``nesti_config_t`` (include/nesti_hip.h)."""
+    _fields_ = [("arch", ctypes.c_int),
+                ("n_scales", ctypes.c_int),
+                ("points_per_scale", ctypes.c_int),
+                ("grid_n", ctypes.c_int),
+                ("variance", ctypes.c_double),
+                ("n_experts", ctypes.c_int),
+                ("expert_scale_lo", ctypes.c_int * MAX_EXPERTS),
+                ("expert_scale_cnt", ctypes.c_int * MAX_EXPERTS)]
+
+
+@dataclass
+class NestiConfig:
+    """Defaults = the trained Nesti-Net command line (train_n_est_w_experts.py:20-64)."""
+    patch_radius: List[float] = field(default_factory=lambda: [0.01, 0.03, 0.05])
+    num_point: int = 512
+    n_gaussians: int = 8          # per axis
+    gmm_variance: float = 0.0156
+    n_experts: int = 7
+    expert_dict: Dict[int, List[int]] = field(default_factory=lambda: dict(TRAINED_EXPERT_DICT))
+    arch: int = ARCH_EXPERTS
+
+    @property
+    def n_scales(self):
+        return len(self.patch_radius)
+
+    def default_expert_dict(self):
+        """``models/experts_n_est.py:83-96`` when expert_dict is None."""
+        n_rads, E = self.n_scales, self.n_experts
+        out = []
+        for i in range(n_rads):
+            out += [[i]] * (E // n_rads)
+        out += [list(range(n_rads))] * (E % n_rads)
+        return {i: out[i] for i in range(E)}
+
+    def to_c(self):
+        c = CConfig()
+        c.arch = self.arch
+        c.n_scales = self.n_scales
+        c.points_per_scale = self.num_point
+        c.grid_n = self.n_gaussians
+        c.variance = float(self.gmm_variance)
+        c.n_experts = self.n_experts
+        ed = self.expert_dict if self.expert_dict is not None else self.default_expert_dict()
+        if len(ed) != self.n_experts:
+            raise ValueError("Incompatible expert assignment values in variable expert_dict")
+        for i in range(self.n_experts):
+            scales = list(ed[i])
+            lo = min(scales)                      # models/experts_n_est.py:100
+            c.expert_scale_lo[i] = lo
+            c.expert_scale_cnt[i] = len(scales)   # models/experts_n_est.py:101
+        return c
+
+    def to_json(self):
+        d = dict(self.__dict__)
+        d["expert_dict"] = {str(k): v for k, v in self.expert_dict.items()}
+        return json.dumps(d)
+
+    @staticmethod
+    def from_json(s):
+        d = json.loads(s)
+        d["expert_dict"] = {int(k): v for k, v in d["expert_dict"].items()}
+        return NestiConfig(**d)

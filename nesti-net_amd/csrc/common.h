@@ -1,0 +1,76 @@
+// Shared helpers for libnesti_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/nesti_hip.h"
+
+namespace nesti {
+
+void set_error(const std::string& msg);
+
+#define NESTI_CHECK_HIP(expr)                                                         \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      ::nesti::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));          \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+
+#define NESTI_FAIL(msg)           \
+  do {                            \
+    ::nesti::set_error(msg);      \
+    return 1;                     \
+  } while (0)
+
+static inline size_t dtype_size(int dt) { return dt == NESTI_F32 ? 4 : 2; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- element conversion (device) ------------------------------------------
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                            // RNE
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
+  return __uint_as_float(((uint32_t)h) << 16);
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+  _Float16 h = (_Float16)f;
+  return *reinterpret_cast<uint16_t*>(&h);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t b) {
+  _Float16 h = *reinterpret_cast<_Float16*>(&b);
+  return (float)h;
+}
+
+template <int DT> struct Elem;
+template <> struct Elem<NESTI_F32> {
+  using T = float;
+  static __device__ __forceinline__ T from_f32(float f) { return f; }
+  static __device__ __forceinline__ float to_f32(T v) { return v; }
+};
+template <> struct Elem<NESTI_BF16> {
+  using T = uint16_t;
+  static __device__ __forceinline__ T from_f32(float f) { return f32_to_bf16_bits(f); }
+  static __device__ __forceinline__ float to_f32(T v) { return bf16_bits_to_f32(v); }
+};
+template <> struct Elem<NESTI_F16> {
+  using T = uint16_t;
+  static __device__ __forceinline__ T from_f32(float f) { return f32_to_f16_bits(f); }
+  static __device__ __forceinline__ float to_f32(T v) { return f16_bits_to_f32(v); }
+};
+
+// host-side conversions used by the weight repacker
+uint16_t host_f32_to_bf16(float f);
+uint16_t host_f32_to_f16(float f);
+
+// ---- launchers implemented in the .hip files -------------------------------
+int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n_eff, int B,
+                void* out, int out_dtype, int out_cstride, hipStream_t stream);
+
+}  // namespace nesti

@@ -1,0 +1,63 @@
+// Kernel parameter blocks and launchers shared between the .hip files and the
+// host-side graph executor (model.hip).
+#pragma once
+#include "common.h"
+
+namespace nesti {
+
+constexpr int kTileM = 512;       // GEMM rows (voxels x points) per workgroup
+constexpr int kRowBytes = 128;    // bytes of one K-chunk row in LDS (64 x 16-bit or 32 x f32)
+constexpr int kMaxTaps = 125;     // 5^3
+
+static inline int chunk_elems(int dt) { return kRowBytes / (int)dtype_size(dt); }  // KC
+
+// One conv3d / fully-connected layer as an implicit GEMM:
+//   out[r, n] = act( sum_{tap, c} in[shift(r, tap), c] * W[tap, c, n] + bias[n] )
+// rows r = point * V + voxel (V = S^3, channels-last); a tap that leaves the S^3 volume
+// contributes zero (TF 'SAME', utils/tf_util.py:298-300).
+struct ConvParams {
+  const void* in;      // [points * V, in_cstride] elements of the model dtype
+  void* out;           // [points * V, out_cstride] (model dtype, or f32 if out_f32)
+  const void* wpk;     // packed weights [n_tiles][n_chunks][n_taps][TN][128 B] (pre-swizzled)
+  const float* bias;   // [n_tiles * TN] BN-folded bias
+  const int32_t* npoints_ptr;   // optional device-side point count (top-1 routing); NULL -> npoints
+  const int32_t* point_index;   // optional gather of INPUT points (routing); NULL -> identity
+  int npoints;         // capacity (grid is sized for this)
+  int in_cstride, in_coff;
+  int out_cstride, out_coff;
+  int n_chunks, n_taps;
+  int log2S;           // S in {1,2,4,8}
+  int relu, out_f32;
+  int m_tiles;
+  int8_t tap[kMaxTaps][4];   // dz, dy, dx, -
+};
+
+int launch_conv(const ConvParams& p, int dtype, int TN, int n_tiles, hipStream_t stream);
+
+struct PoolParams {
+  const void* in;
+  void* out;
+  const int32_t* npoints_ptr;
+  const int32_t* point_index;   // gather of INPUT points (avg pool only)
+  int npoints;
+  int in_cstride, in_coff, out_cstride, out_coff;
+  int C;               // channels to process (multiple of 8)
+  int log2S;           // input S
+  int k;               // avg: window; max: ignored (2^3 stride 2)
+};
+int launch_avgpool(const PoolParams& p, int dtype, hipStream_t stream);
+int launch_maxpool2(const PoolParams& p, int dtype, hipStream_t stream);
+
+// softmax over the first E logits of each row + first-index arg-max
+// (models/experts_n_est.py:177, test_n_est_w_experts.py:150); optional routing lists.
+int launch_gate_finish(const float* logits, int lstride, int B, int E, float* probs,
+                       int32_t* expert, int32_t* counts /*[E] or NULL*/,
+                       int32_t* lists /*[E][B] or NULL*/, hipStream_t stream);
+// build routing lists from a caller-supplied expert assignment
+int launch_route(const int32_t* expert, int B, int E, int32_t* counts, int32_t* lists,
+                 hipStream_t stream);
+// out[index[j]*3 + c] = src[j*sstride + c] for j < *count (or count_cap when count_ptr NULL)
+int launch_scatter3(const float* src, int sstride, const int32_t* index, const int32_t* count_ptr,
+                    int count_cap, float* out, hipStream_t stream);
+
+}  // namespace nesti

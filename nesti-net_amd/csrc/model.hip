@@ -1,0 +1,643 @@
+// Host side of libnesti_hip.so: C-ABI entry points, the Nesti-Net graph
+// (models/experts_n_est.py:40-314) expressed as a list of kernel launches, batch-norm folding
+// and weight repacking for the MFMA kernels, and the workspace planner.
+#include <math.h>
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace nesti {
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+
+uint16_t host_f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+uint16_t host_f32_to_f16(float f) {
+  _Float16 h = (_Float16)f;   // clang host: IEEE RNE conversion
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  return b;
+}
+
+namespace {
+
+constexpr int kPad = 64;   // channel segments are zero-padded to multiples of this
+inline int pad_to(int c, int a) { return (c + a - 1) / a * a; }
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// ------------------------------------------------------------------------------------------
+// graph description
+// ------------------------------------------------------------------------------------------
+struct LayerDesc {
+  std::string scope;
+  bool is_fc = false;
+  int k = 1;                 // kernel size (1 for fc)
+  int log2S = 0;             // spatial size the layer runs at
+  int cin = 0, cout = 0;     // real channel counts (TF variable shapes)
+  std::vector<int> in_pos;   // real input channel -> position inside the padded input slice
+  int Cin_p = 0, Cout_p = 0;
+  bool bn = true, relu = true;
+};
+
+struct BufSpec { int log2S; int C; bool f32; };
+
+struct Op {
+  enum Kind { CONV, AVG, MAX } kind;
+  int in_buf = 0, in_coff = 0, out_buf = 0, out_coff = 0;
+  int layer = -1;
+  int C = 0, k = 0, log2S = 0;
+  bool out_f32 = false;
+};
+
+struct Tower {
+  std::vector<BufSpec> bufs;   // bufs[0] = MuPS X0, bufs[1] = avg-pooled MuPS P0 (both external)
+  std::vector<Op> ops;
+  int out_buf = -1;            // f32 [NB, 64]
+  int n_out = 0;               // real outputs (E or 3)
+};
+
+struct ChanMap { std::vector<int> pos; int C = 0; };   // real channel -> padded position, padded width
+
+struct Graph {
+  nesti_config_t cfg;
+  int mups_cstride = 64;
+  std::vector<LayerDesc> layers;
+  Tower gate;
+  std::vector<Tower> experts;
+};
+
+struct Builder {
+  Graph& g;
+  explicit Builder(Graph& gg) : g(gg) {}
+
+  int add_layer(const LayerDesc& d) { g.layers.push_back(d); return (int)g.layers.size() - 1; }
+
+  int conv(Tower& T, const std::string& scope, int k, int log2S, int in_buf, int in_coff, const ChanMap& in,
+           int cout, int out_buf, int out_coff, bool bn = true, bool relu = true, bool fc = false, bool out_f32 = false) {
+    LayerDesc d;
+    d.scope = scope; d.is_fc = fc; d.k = k; d.log2S = log2S;
+    d.cin = (int)in.pos.size(); d.cout = cout; d.in_pos = in.pos; d.Cin_p = in.C;
+    d.Cout_p = pad_to(cout, kPad); d.bn = bn; d.relu = relu;
+    Op op; op.kind = Op::CONV; op.in_buf = in_buf; op.in_coff = in_coff; op.out_buf = out_buf; op.out_coff = out_coff;
+    op.layer = add_layer(d); op.log2S = log2S; op.out_f32 = out_f32;
+    T.ops.push_back(op);
+    return d.Cout_p;
+  }
+
+  // models/experts_n_est.py:294-314.  pooled_buf < 0: create the avg-pooled copy here.
+  int inception(Tower& T, const std::string& scope, int in_buf, const ChanMap& in, int pooled_buf, int F, int k0,
+                int k1, int log2S, ChanMap* out_map) {
+    const int H = F / 2;   // int(n_filters/2)  :299
+    const int Fp = pad_to(F, kPad), Hp = pad_to(H, kPad);
+    const int C = Fp + Hp + Hp + Fp;
+    T.bufs.push_back({log2S, C, false});
+    const int ob = (int)T.bufs.size() - 1;
+    ChanMap c1; c1.C = Fp; for (int i = 0; i < F; ++i) c1.pos.push_back(i);
+    conv(T, scope + "_conv1", 1, log2S, in_buf, 0, in, F, ob, 0);
+    conv(T, scope + "_conv2", k0, log2S, ob, 0, c1, H, ob, Fp);
+    conv(T, scope + "_conv3", k1, log2S, ob, 0, c1, H, ob, Fp + Hp);
+    int pb = pooled_buf;
+    if (k0 == 1) pb = in_buf;   // avg_pool3d with a 1^3 window is the identity (:307)
+    else if (pb < 0) {
+      T.bufs.push_back({log2S, in.C, false});
+      pb = (int)T.bufs.size() - 1;
+      Op op; op.kind = Op::AVG; op.in_buf = in_buf; op.out_buf = pb; op.C = in.C; op.k = k0; op.log2S = log2S;
+      T.ops.push_back(op);
+    }
+    conv(T, scope + "_conv4", 1, log2S, pb, 0, in, F, ob, Fp + Hp + Hp);
+    out_map->pos.clear();
+    for (int i = 0; i < F; ++i) out_map->pos.push_back(i);
+    for (int i = 0; i < H; ++i) out_map->pos.push_back(Fp + i);
+    for (int i = 0; i < H; ++i) out_map->pos.push_back(Fp + Hp + i);
+    for (int i = 0; i < F; ++i) out_map->pos.push_back(Fp + Hp + Hp + i);
+    out_map->C = C;
+    return ob;
+  }
+
+  int maxpool(Tower& T, int in_buf, const ChanMap& m, int log2S) {
+    T.bufs.push_back({log2S - 1, m.C, false});
+    const int ob = (int)T.bufs.size() - 1;
+    Op op; op.kind = Op::MAX; op.in_buf = in_buf; op.out_buf = ob; op.C = m.C; op.log2S = log2S;
+    T.ops.push_back(op);
+    return ob;
+  }
+
+  // fully connected stack on a [NB,1,C] feature (utils/tf_util.py:314-351)
+  int fc_stack(Tower& T, int in_buf, ChanMap m, const std::vector<std::string>& scopes, const std::vector<int>& widths,
+               bool last_relu) {
+    int buf = in_buf;
+    for (size_t i = 0; i < scopes.size(); ++i) {
+      const bool last = (i + 1 == scopes.size());
+      const int Cp = pad_to(widths[i], kPad);
+      T.bufs.push_back({0, Cp, last});
+      const int ob = (int)T.bufs.size() - 1;
+      conv(T, scopes[i], 1, 0, buf, 0, m, widths[i], ob, 0, /*bn=*/!last, /*relu=*/last ? last_relu : true, /*fc=*/true,
+           /*out_f32=*/last);
+      m.pos.clear(); m.C = Cp;
+      for (int c = 0; c < widths[i]; ++c) m.pos.push_back(c);
+      buf = ob;
+    }
+    return buf;
+  }
+
+  void init_tower(Tower& T) {
+    T.bufs.clear(); T.ops.clear();
+    T.bufs.push_back({3, g.mups_cstride, false});   // 0: X0
+    T.bufs.push_back({3, g.mups_cstride, false});   // 1: P0 = avg_pool3(X0)
+  }
+
+  // scale_manager_net + conv_net_8g (models/experts_n_est.py:155-215)
+  void build_gate() {
+    Tower& T = g.gate;
+    init_tower(T);
+    const int S = g.cfg.n_scales;
+    ChanMap m; m.C = g.mups_cstride;
+    for (int c = 0; c < 20 * S; ++c) m.pos.push_back(c);
+    const std::string s = "gating_conv";
+    int b = inception(T, "inception1" + s, 0, m, 1, 128, 3, 5, 3, &m);
+    b = inception(T, "inception2" + s, b, m, -1, 256, 3, 5, 3, &m);
+    b = inception(T, "inception3" + s, b, m, -1, 256, 3, 5, 3, &m);
+    b = maxpool(T, b, m, 3);
+    b = inception(T, "inception5" + s, b, m, -1, 512, 2, 4, 2, &m);
+    b = inception(T, "inception6" + s, b, m, -1, 512, 2, 4, 2, &m);
+    b = maxpool(T, b, m, 2);
+    b = inception(T, "inception8" + s, b, m, -1, 512, 1, 2, 1, &m);
+    b = maxpool(T, b, m, 1);
+    T.out_buf = fc_stack(T, b, m, {"fc1noise", "fc2noise", "fc3noise", "fc4noise"}, {1024, 256, 128, g.cfg.n_experts},
+                         /*last_relu=*/true);   // relu on fc4: models/experts_n_est.py:174
+    T.n_out = g.cfg.n_experts;
+  }
+
+  // normal_est_net, 8^3 branch (models/experts_n_est.py:243-291)
+  void build_expert(int i) {
+    Tower& T = g.experts[i];
+    init_tower(T);
+    const int lo = g.cfg.expert_scale_lo[i], cnt = g.cfg.expert_scale_cnt[i];
+    ChanMap m; m.C = g.mups_cstride;
+    for (int c = 0; c < 20 * cnt; ++c) m.pos.push_back(20 * lo + c);   // MuPS[..., start:end]  :100-102
+    const std::string s = "Expert_" + std::to_string(i);
+    const int F1 = 128 / cnt;   // np.round(128 / divider) under Python-2 integer division  :254
+    int b = inception(T, "inception1" + s, 0, m, 1, F1, 3, 5, 3, &m);
+    b = inception(T, "inception2" + s, b, m, -1, 256, 3, 5, 3, &m);
+    b = maxpool(T, b, m, 3);
+    b = inception(T, "inception4" + s, b, m, -1, 256, 2, 4, 2, &m);
+    b = maxpool(T, b, m, 2);
+    b = inception(T, "inception6" + s, b, m, -1, 512, 2, 4, 1, &m);
+    b = maxpool(T, b, m, 1);
+    T.out_buf = fc_stack(T, b, m, {"fc1" + s, "fc2" + s, "fc3" + s, "fc4" + s}, {512, 128, 64, 3}, /*last_relu=*/false);
+    T.n_out = 3;
+  }
+};
+
+int build_graph(const nesti_config_t* cfg, Graph* g) {
+  if (cfg->arch != NESTI_ARCH_EXPERTS) NESTI_FAIL("only NESTI_ARCH_EXPERTS is implemented in this build");
+  if (cfg->grid_n != 8) NESTI_FAIL("only the 8^3 Gaussian grid is implemented");
+  if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("bad n_scales");
+  if (cfg->n_experts < 1 || cfg->n_experts > NESTI_MAX_EXPERTS) NESTI_FAIL("bad n_experts");
+  for (int i = 0; i < cfg->n_experts; ++i) {
+    if (cfg->expert_scale_cnt[i] < 1 || cfg->expert_scale_lo[i] < 0 ||
+        cfg->expert_scale_lo[i] + cfg->expert_scale_cnt[i] > cfg->n_scales)
+      NESTI_FAIL("expert scale range outside [0, n_scales)");
+  }
+  g->cfg = *cfg;
+  g->mups_cstride = pad_to(20 * cfg->n_scales, kPad);
+  g->layers.clear();
+  Builder b(*g);
+  b.build_gate();
+  g->experts.assign(cfg->n_experts, Tower());
+  for (int i = 0; i < cfg->n_experts; ++i) b.build_expert(i);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// device-resident packed layers
+// ------------------------------------------------------------------------------------------
+struct PackedLayer {
+  void* wpk = nullptr;
+  float* bias = nullptr;
+  int TN = 64, n_tiles = 0, n_chunks = 0, n_taps = 0;
+  int8_t tap[kMaxTaps][4];
+};
+
+}  // namespace
+}  // namespace nesti
+
+struct nesti_model {
+  nesti::Graph graph;
+  int dtype = NESTI_BF16;
+  std::vector<nesti::PackedLayer> packed;
+  ~nesti_model() {
+    for (auto& p : packed) {
+      if (p.wpk) (void)hipFree(p.wpk);
+      if (p.bias) (void)hipFree(p.bias);
+    }
+  }
+};
+
+namespace nesti {
+namespace {
+
+struct TensorTable {
+  std::map<std::string, const nesti_tensor_t*> by_name;
+  const nesti_tensor_t* get(const std::string& n) const {
+    auto it = by_name.find(n);
+    return it == by_name.end() ? nullptr : it->second;
+  }
+};
+
+bool shape_is(const nesti_tensor_t* t, std::initializer_list<int64_t> dims) {
+  if (!t || !t->data || t->ndim != (int)dims.size()) return false;
+  int i = 0;
+  for (int64_t d : dims) if (t->dims[i++] != d) return false;
+  return true;
+}
+
+// Expected variables of one layer, in TF naming (utils/tf_util.py:289-302, 332-342, 473-479).
+void layer_tensors(const LayerDesc& d, std::vector<std::pair<std::string, std::vector<int64_t>>>* out) {
+  if (d.is_fc) out->push_back({d.scope + "/weights", {d.cin, d.cout}});
+  else out->push_back({d.scope + "/weights", {d.k, d.k, d.k, d.cin, d.cout}});
+  out->push_back({d.scope + "/biases", {d.cout}});
+  if (d.bn) {
+    for (const char* n : {"beta", "gamma", "mean", "var"}) out->push_back({d.scope + "/bn/" + n, {d.cout}});
+  }
+}
+
+int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer* pl) {
+  const nesti_tensor_t* w = tt.get(d.scope + "/weights");
+  const nesti_tensor_t* b = tt.get(d.scope + "/biases");
+  const bool wok = d.is_fc ? shape_is(w, {d.cin, d.cout}) : shape_is(w, {d.k, d.k, d.k, d.cin, d.cout});
+  if (!wok) NESTI_FAIL("missing or mis-shaped tensor " + d.scope + "/weights");
+  if (!shape_is(b, {d.cout})) NESTI_FAIL("missing or mis-shaped tensor " + d.scope + "/biases");
+  std::vector<float> scale(d.cout, 1.0f), bias(d.cout);
+  for (int n = 0; n < d.cout; ++n) bias[n] = b->data[n];
+  if (d.bn) {
+    const nesti_tensor_t* beta = tt.get(d.scope + "/bn/beta");
+    const nesti_tensor_t* gamma = tt.get(d.scope + "/bn/gamma");
+    const nesti_tensor_t* mean = tt.get(d.scope + "/bn/mean");
+    const nesti_tensor_t* var = tt.get(d.scope + "/bn/var");
+    if (!shape_is(beta, {d.cout}) || !shape_is(gamma, {d.cout}) || !shape_is(mean, {d.cout}) || !shape_is(var, {d.cout}))
+      NESTI_FAIL("missing or mis-shaped batch-norm tensors under " + d.scope + "/bn/");
+    for (int n = 0; n < d.cout; ++n) {
+      // tf.nn.batch_normalization(x, mean, var, beta, gamma, 1e-3)  (utils/tf_util.py:494)
+      const double inv = (double)gamma->data[n] / sqrt((double)var->data[n] + 1e-3);
+      scale[n] = (float)inv;
+      bias[n] = (float)(((double)b->data[n] - (double)mean->data[n]) * inv + (double)beta->data[n]);
+    }
+  }
+  const int S = 1 << d.log2S;
+  const int lo = (d.k - 1) / 2;   // TF SAME, stride 1
+  pl->n_taps = 0;
+  std::vector<int> tap_widx;
+  for (int a = 0; a < d.k; ++a)
+    for (int bb = 0; bb < d.k; ++bb)
+      for (int c = 0; c < d.k; ++c) {
+        const int dz = a - lo, dy = bb - lo, dx = c - lo;
+        if (abs(dz) >= S || abs(dy) >= S || abs(dx) >= S) continue;   // never lands inside the volume
+        pl->tap[pl->n_taps][0] = (int8_t)dz; pl->tap[pl->n_taps][1] = (int8_t)dy;
+        pl->tap[pl->n_taps][2] = (int8_t)dx; pl->tap[pl->n_taps][3] = 0;
+        tap_widx.push_back((a * d.k + bb) * d.k + c);
+        ++pl->n_taps;
+      }
+  const int KC = chunk_elems(dtype);
+  const size_t esz = dtype_size(dtype);
+  pl->TN = (d.Cout_p % 128 == 0) ? 128 : 64;
+  pl->n_tiles = d.Cout_p / pl->TN;
+  pl->n_chunks = d.Cin_p / KC;
+  if (d.Cin_p % KC) NESTI_FAIL("internal: Cin_p not a multiple of the K chunk");
+  std::vector<int> inv(d.Cin_p, -1);
+  for (int c = 0; c < d.cin; ++c) inv[d.in_pos[c]] = c;
+  const size_t tile_bytes = (size_t)pl->TN * kRowBytes;
+  const size_t total = (size_t)pl->n_tiles * pl->n_chunks * pl->n_taps * tile_bytes;
+  std::vector<unsigned char> host(total, 0);
+  const int per_slot = 16 / (int)esz;
+  for (int nt = 0; nt < pl->n_tiles; ++nt)
+    for (int ch = 0; ch < pl->n_chunks; ++ch)
+      for (int t = 0; t < pl->n_taps; ++t) {
+        unsigned char* tile = host.data() + (((size_t)nt * pl->n_chunks + ch) * pl->n_taps + t) * tile_bytes;
+        const float* wt = w->data + (size_t)tap_widx[t] * d.cin * d.cout;
+        for (int kc = 0; kc < KC; ++kc) {
+          const int cr = inv[ch * KC + kc];
+          if (cr < 0) continue;
+          const float* wrow = wt + (size_t)cr * d.cout;
+          const int slot = kc / per_slot, within = kc % per_slot;
+          for (int nl = 0; nl < pl->TN; ++nl) {
+            const int n = nt * pl->TN + nl;
+            if (n >= d.cout) break;
+            const float v = wrow[n] * scale[n];
+            unsigned char* dst = tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
+            if (dtype == NESTI_F32) memcpy(dst, &v, 4);
+            else {
+              const uint16_t h = (dtype == NESTI_BF16) ? host_f32_to_bf16(v) : host_f32_to_f16(v);
+              memcpy(dst, &h, 2);
+            }
+          }
+        }
+      }
+  std::vector<float> bias_p((size_t)pl->n_tiles * pl->TN, 0.f);
+  for (int n = 0; n < d.cout; ++n) bias_p[n] = bias[n];
+  NESTI_CHECK_HIP(hipMalloc(&pl->wpk, total));
+  NESTI_CHECK_HIP(hipMemcpy(pl->wpk, host.data(), total, hipMemcpyHostToDevice));
+  NESTI_CHECK_HIP(hipMalloc((void**)&pl->bias, bias_p.size() * sizeof(float)));
+  NESTI_CHECK_HIP(hipMemcpy(pl->bias, bias_p.data(), bias_p.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace planning and tower execution
+// ------------------------------------------------------------------------------------------
+size_t buf_bytes(const BufSpec& b, int NB, int dtype) {
+  const size_t e = b.f32 ? 4 : dtype_size(dtype);
+  return align_up(((size_t)NB << (3 * b.log2S)) * b.C * e, 256);
+}
+size_t tower_bytes(const Tower& T, int NB, int dtype) {
+  size_t s = 0;
+  for (size_t i = 2; i < T.bufs.size(); ++i) s += buf_bytes(T.bufs[i], NB, dtype);
+  return s;
+}
+
+struct RunCtx {
+  const nesti_model* m;
+  int NB;                        // capacity (points)
+  const int32_t* npoints_ptr;    // device-side live count or NULL
+  const int32_t* point_index;    // gather for reads of bufs 0/1, or NULL
+  hipStream_t stream;
+};
+
+int run_tower(const RunCtx& rc, const Tower& T, const void* X0, const void* P0, unsigned char* ws, size_t ws_bytes,
+              float** out) {
+  const int dtype = rc.m->dtype;
+  std::vector<unsigned char*> ptr(T.bufs.size(), nullptr);
+  ptr[0] = (unsigned char*)X0;
+  ptr[1] = (unsigned char*)P0;
+  size_t off = 0;
+  for (size_t i = 2; i < T.bufs.size(); ++i) {
+    ptr[i] = ws + off;
+    off += buf_bytes(T.bufs[i], rc.NB, dtype);
+  }
+  if (off > ws_bytes) NESTI_FAIL("workspace too small for this batch");
+  for (const Op& op : T.ops) {
+    const bool ext_in = op.in_buf < 2;
+    if (op.kind == Op::CONV) {
+      const LayerDesc& d = rc.m->graph.layers[op.layer];
+      const PackedLayer& pl = rc.m->packed[op.layer];
+      ConvParams p;
+      memset(&p, 0, sizeof(p));
+      p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf]; p.wpk = pl.wpk; p.bias = pl.bias;
+      p.npoints_ptr = rc.npoints_ptr; p.point_index = ext_in ? rc.point_index : nullptr;
+      p.npoints = rc.NB;
+      p.in_cstride = T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
+      p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
+      p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S;
+      p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
+      const long long rows = (long long)rc.NB << (3 * d.log2S);
+      p.m_tiles = (int)((rows + kTileM - 1) / kTileM);
+      memcpy(p.tap, pl.tap, sizeof(p.tap));
+      if (launch_conv(p, dtype, pl.TN, pl.n_tiles, rc.stream)) return 1;
+    } else {
+      PoolParams p;
+      memset(&p, 0, sizeof(p));
+      p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf];
+      p.npoints_ptr = rc.npoints_ptr; p.point_index = ext_in ? rc.point_index : nullptr;
+      p.npoints = rc.NB;
+      p.in_cstride = T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
+      p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
+      p.C = op.C; p.log2S = op.log2S; p.k = op.k;
+      if (op.kind == Op::AVG) { if (launch_avgpool(p, dtype, rc.stream)) return 1; }
+      else { if (launch_maxpool2(p, dtype, rc.stream)) return 1; }
+    }
+  }
+  *out = reinterpret_cast<float*>(ptr[T.out_buf]);
+  return 0;
+}
+
+// avg_pool3d(MuPS, 3^3): shared by the gate's and every expert's first inception (their input and k0 coincide)
+int pool_mups(const nesti_model* m, const void* X0, void* P0, int B, hipStream_t stream) {
+  PoolParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = X0; p.out = P0; p.npoints = B;
+  p.in_cstride = p.out_cstride = p.C = m->graph.mups_cstride;
+  p.log2S = 3; p.k = 3;
+  return launch_avgpool(p, m->dtype, stream);
+}
+
+size_t max_tower_bytes(const nesti_model* m, int NB) {
+  size_t t = tower_bytes(m->graph.gate, NB, m->dtype);
+  for (const Tower& e : m->graph.experts) t = std::max(t, tower_bytes(e, NB, m->dtype));
+  return t;
+}
+
+struct WsLayout {
+  size_t x0, p0, probs, expert, counts, lists, tower, total;
+};
+WsLayout ws_layout(const nesti_model* m, int NB) {
+  WsLayout L;
+  const size_t act = align_up(((size_t)NB << 9) * m->graph.mups_cstride * dtype_size(m->dtype), 256);
+  size_t o = 0;
+  L.x0 = o; o += act;
+  L.p0 = o; o += act;
+  L.probs = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
+  L.expert = o; o += align_up((size_t)NB * 4, 256);
+  L.counts = o; o += 256;
+  L.lists = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
+  L.tower = o; o += max_tower_bytes(m, NB);
+  L.total = o;
+  return L;
+}
+
+int gate_impl(const nesti_model* m, const void* X0, const void* P0, int B, unsigned char* tower_ws, size_t tower_bytes_,
+              float* probs, int32_t* expert, int32_t* counts, int32_t* lists, hipStream_t stream) {
+  RunCtx rc{m, B, nullptr, nullptr, stream};
+  float* logits = nullptr;
+  if (run_tower(rc, m->graph.gate, X0, P0, tower_ws, tower_bytes_, &logits)) return 1;
+  const int lstride = m->graph.gate.bufs[m->graph.gate.out_buf].C;
+  return launch_gate_finish(logits, lstride, B, m->graph.cfg.n_experts, probs, expert, counts, lists, stream);
+}
+
+int experts_impl(const nesti_model* m, const void* X0, const void* P0, int B, unsigned char* tower_ws, size_t tower_bytes_,
+                 const int32_t* counts, const int32_t* lists, float* normals, hipStream_t stream) {
+  const int E = m->graph.cfg.n_experts;
+  for (int e = 0; e < E; ++e) {
+    const Tower& T = m->graph.experts[e];
+    float* out = nullptr;
+    const int ostride = T.bufs[T.out_buf].C;
+    if (counts) {   // top-1 routing: only the points whose arg-max is e (test_n_est_w_experts.py:150-152)
+      RunCtx rc{m, B, counts + e, lists + (size_t)e * B, stream};
+      if (run_tower(rc, T, X0, P0, tower_ws, tower_bytes_, &out)) return 1;
+      if (launch_scatter3(out, ostride, lists + (size_t)e * B, counts + e, B, normals, stream)) return 1;
+    } else {        // reference behaviour: every expert on every point -> [E,B,3]
+      RunCtx rc{m, B, nullptr, nullptr, stream};
+      if (run_tower(rc, T, X0, P0, tower_ws, tower_bytes_, &out)) return 1;
+      if (launch_scatter3(out, ostride, nullptr, nullptr, B, normals + (size_t)e * B * 3, stream)) return 1;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+}  // namespace nesti
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+using namespace nesti;
+
+extern "C" {
+
+const char* nesti_last_error(void) { return g_error.c_str(); }
+const char* nesti_version(void) { return "nesti-hip 0.1 (gfx950)"; }
+
+void nesti_default_config(nesti_config_t* cfg) {
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->arch = NESTI_ARCH_EXPERTS;
+  cfg->n_scales = 3;                 // --patch_radius 0.01 0.03 0.05   train_n_est_w_experts.py:20
+  cfg->points_per_scale = 512;       // --num_point
+  cfg->grid_n = 8;                   // --n_gaussians 8
+  cfg->variance = 0.0156;            // --gmm_variance
+  cfg->n_experts = 7;
+  const int lo[7] = {0, 0, 1, 1, 2, 2, 0}, cnt[7] = {1, 1, 1, 1, 1, 1, 3};   // expert_dict  :62
+  for (int i = 0; i < 7; ++i) { cfg->expert_scale_lo[i] = lo[i]; cfg->expert_scale_cnt[i] = cnt[i]; }
+}
+
+int nesti_gmm_grid(int n, double variance, float* w, float* mu, float* sigma) {
+  if (n < 1 || !w || !mu || !sigma) NESTI_FAIL("nesti_gmm_grid: bad arguments");
+  // np.mgrid[step-1 : 1-step : n j] per axis, reshape [3,-1].T  => x slowest (utils/utils.py:81-87)
+  const double step = 1.0 / n;
+  const double a0 = step - 1.0, a1 = 1.0 - step;
+  const int G = n * n * n;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      for (int k = 0; k < n; ++k) {
+        const int g = (i * n + j) * n + k;
+        const int idx[3] = {i, j, k};
+        for (int c = 0; c < 3; ++c) {
+          const double v = (n == 1) ? a0 : a0 + (a1 - a0) * idx[c] / (double)(n - 1);
+          mu[g * 3 + c] = (float)v;
+          sigma[g * 3 + c] = (float)sqrt(variance);   // np.sqrt(gmm.covariances_)  test_n_est_w_experts.py:146
+        }
+        w[g] = (float)(1.0 / G);                       // utils/utils.py:89
+      }
+  return 0;
+}
+
+int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev, const int32_t* n_eff_dev, int B,
+                       void* out_dev, int out_dtype, int out_cstride, void* stream) {
+  if (!cfg || !points_dev || !n_eff_dev || !out_dev) NESTI_FAIL("nesti_mups_forward: null argument");
+  return launch_mups(cfg, points_dev, n_eff_dev, B, out_dev, out_dtype, out_cstride, (hipStream_t)stream);
+}
+
+int nesti_model_describe(const nesti_config_t* cfg, int* n_tensors, nesti_tensor_t* infos, int max_infos) {
+  if (!cfg || !n_tensors) NESTI_FAIL("nesti_model_describe: null argument");
+  Graph g;
+  if (build_graph(cfg, &g)) return 1;
+  static thread_local std::vector<std::string> names;
+  std::vector<std::pair<std::string, std::vector<int64_t>>> all;
+  for (const LayerDesc& d : g.layers) layer_tensors(d, &all);
+  *n_tensors = (int)all.size();
+  if (!infos) return 0;
+  if (max_infos < (int)all.size()) NESTI_FAIL("nesti_model_describe: infos array too small");
+  names.clear();
+  names.reserve(all.size());
+  for (size_t i = 0; i < all.size(); ++i) {
+    names.push_back(all[i].first);
+    infos[i].name = names.back().c_str();
+    infos[i].data = nullptr;
+    infos[i].ndim = (int)all[i].second.size();
+    for (int d = 0; d < 5; ++d) infos[i].dims[d] = d < infos[i].ndim ? all[i].second[d] : 0;
+  }
+  return 0;
+}
+
+int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors, int n_tensors, int dtype,
+                       nesti_model_t** out) {
+  if (!cfg || !tensors || !out) NESTI_FAIL("nesti_model_create: null argument");
+  if (dtype != NESTI_F32 && dtype != NESTI_BF16 && dtype != NESTI_F16) NESTI_FAIL("nesti_model_create: bad dtype");
+  std::unique_ptr<nesti_model> m(new nesti_model());
+  m->dtype = dtype;
+  if (build_graph(cfg, &m->graph)) return 1;
+  TensorTable tt;
+  for (int i = 0; i < n_tensors; ++i) if (tensors[i].name) tt.by_name[tensors[i].name] = &tensors[i];
+  m->packed.resize(m->graph.layers.size());
+  for (size_t i = 0; i < m->graph.layers.size(); ++i)
+    if (pack_layer(m->graph.layers[i], tt, dtype, &m->packed[i])) return 1;
+  NESTI_CHECK_HIP(hipDeviceSynchronize());
+  *out = m.release();
+  return 0;
+}
+
+void nesti_model_destroy(nesti_model_t* m) { delete m; }
+
+size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch) {
+  if (!m || max_batch <= 0) return 0;
+  return ws_layout(m, max_batch).total;
+}
+
+int nesti_model_mups_cstride(const nesti_model_t* m) { return m ? m->graph.mups_cstride : 0; }
+
+int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void* ws_dev, size_t ws_bytes,
+                       float* probs_out_dev, int32_t* expert_out_dev, void* stream) {
+  if (!m || !mups_dev || !ws_dev) NESTI_FAIL("nesti_gate_forward: null argument");
+  if (B <= 0) return 0;
+  const WsLayout L = ws_layout(m, B);
+  if (L.total > ws_bytes) NESTI_FAIL("nesti_gate_forward: workspace too small (see nesti_workspace_bytes)");
+  unsigned char* ws = (unsigned char*)ws_dev;
+  hipStream_t st = (hipStream_t)stream;
+  if (pool_mups(m, mups_dev, ws + L.p0, B, st)) return 1;
+  return gate_impl(m, mups_dev, ws + L.p0, B, ws + L.tower, L.total - L.tower, probs_out_dev, expert_out_dev, nullptr,
+                   nullptr, st);
+}
+
+int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const int32_t* expert_dev, int B, void* ws_dev,
+                          size_t ws_bytes, float* normals_out_dev, void* stream) {
+  if (!m || !mups_dev || !ws_dev || !normals_out_dev) NESTI_FAIL("nesti_experts_forward: null argument");
+  if (B <= 0) return 0;
+  const WsLayout L = ws_layout(m, B);
+  if (L.total > ws_bytes) NESTI_FAIL("nesti_experts_forward: workspace too small (see nesti_workspace_bytes)");
+  unsigned char* ws = (unsigned char*)ws_dev;
+  hipStream_t st = (hipStream_t)stream;
+  if (pool_mups(m, mups_dev, ws + L.p0, B, st)) return 1;
+  int32_t* counts = nullptr;
+  int32_t* lists = nullptr;
+  if (expert_dev) {
+    counts = (int32_t*)(ws + L.counts);
+    lists = (int32_t*)(ws + L.lists);
+    if (launch_route(expert_dev, B, m->graph.cfg.n_experts, counts, lists, st)) return 1;
+  }
+  return experts_impl(m, mups_dev, ws + L.p0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
+}
+
+int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B, void* ws_dev,
+                  size_t ws_bytes, float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, void* stream) {
+  if (!m || !points_dev || !n_eff_dev || !ws_dev || !normals_out_dev) NESTI_FAIL("nesti_forward: null argument");
+  if (B <= 0) return 0;
+  const WsLayout L = ws_layout(m, B);
+  if (L.total > ws_bytes) NESTI_FAIL("nesti_forward: workspace too small (see nesti_workspace_bytes)");
+  unsigned char* ws = (unsigned char*)ws_dev;
+  hipStream_t st = (hipStream_t)stream;
+  void* X0 = ws + L.x0;
+  void* P0 = ws + L.p0;
+  if (launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride, st)) return 1;
+  if (pool_mups(m, X0, P0, B, st)) return 1;
+  float* probs = probs_out_dev ? probs_out_dev : (float*)(ws + L.probs);
+  int32_t* expert = expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert);
+  int32_t* counts = (int32_t*)(ws + L.counts);
+  int32_t* lists = (int32_t*)(ws + L.lists);
+  if (gate_impl(m, X0, P0, B, ws + L.tower, L.total - L.tower, probs, expert, counts, lists, st)) return 1;
+  return experts_impl(m, X0, P0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
+}
+
+}  // extern "C"

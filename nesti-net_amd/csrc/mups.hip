@@ -1,0 +1,260 @@
+// MuPS (multi-scale point statistics) kernel for gfx950.
+//
+// Computes what utils/tf_util.py:655-753 (get_3dmfv_n_est) + models/experts_n_est.py:66-76
+// compute, but never materialises the [B,P,G,3] broadcast tensors the TF graph
+// builds (utils/tf_util.py:671-678).  On the reference's uniform product grid with
+// isotropic sigma the posterior factorises per axis, Q_ijk = qx_i * qy_j * qz_k
+// (SURVEY.md §8(a')), so one patch point costs 24 exp instead of 512.
+//
+// Mapping: one 256-thread workgroup per query point; thread t owns the two
+// Gaussians (i0, j, k) and (i0+4, j, k) with k = t&7, j = (t>>3)&7, i0 = t>>6
+// (flat Gaussian index 64*i + 8*j + k, x slowest -- utils/utils.py:84-87) and
+// keeps their 2x20 running max/min/sum statistics in registers.  Patch points
+// are processed in chunks of 64: the per-axis terms (q, d, d^2-1) of a chunk are
+// produced by 192 threads into LDS, then every thread sweeps the chunk with
+// broadcast ds_read_b128s.  The kernel is fp32-VALU bound.
+#include "common.h"
+
+namespace nesti {
+
+namespace {
+
+constexpr int kR = 8;          // Gaussians per axis
+constexpr int kG = kR * kR * kR;
+constexpr int kChunk = 64;     // patch points staged per sweep
+constexpr int kThreads = 256;
+
+struct Stats {
+  float sq, mq;                 // sum Q, max Q
+  float mu_max[3], mu_min[3], mu_sum[3];
+  float sg_max[3], sg_min[3], sg_sum[3];
+  __device__ __forceinline__ void init() {
+    sq = 0.f;
+    mq = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mu_max[c] = -INFINITY; mu_min[c] = INFINITY; mu_sum[c] = 0.f;
+      sg_max[c] = -INFINITY; sg_min[c] = INFINITY; sg_sum[c] = 0.f;
+    }
+  }
+  // Q = posterior; d[c] = (x_c - mu_c)/sigma; e[c] = d[c]^2 - 1
+  __device__ __forceinline__ void update(float Q, const float (&d)[3], const float (&e)[3]) {
+    sq += Q;
+    mq = fmaxf(mq, Q);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float m = Q * d[c];                      // utils/tf_util.py:713
+      mu_max[c] = fmaxf(mu_max[c], m);
+      mu_min[c] = fminf(mu_min[c], m);
+      mu_sum[c] += m;
+      const float v = Q * e[c];                      // utils/tf_util.py:717
+      sg_max[c] = fmaxf(sg_max[c], v);
+      sg_min[c] = fminf(sg_min[c], v);
+      sg_sum[c] += v;
+    }
+  }
+};
+
+__device__ __forceinline__ float signed_sqrt(float v) {   // utils/tf_util.py:732-735, alpha = 0.5
+  return copysignf(sqrtf(fabsf(v)), v);
+}
+
+template <int DT>
+__device__ __forceinline__ void store20(void* out, size_t elem_off, const float (&v)[20]) {
+  using E = Elem<DT>;
+  if constexpr (DT == NESTI_F32) {
+    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + elem_off);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) p[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  } else {
+    uint2* p = reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + elem_off);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      uint32_t lo = (uint32_t)E::from_f32(v[4 * q]) | ((uint32_t)E::from_f32(v[4 * q + 1]) << 16);
+      uint32_t hi = (uint32_t)E::from_f32(v[4 * q + 2]) | ((uint32_t)E::from_f32(v[4 * q + 3]) << 16);
+      p[q] = make_uint2(lo, hi);
+    }
+  }
+}
+
+// Turn raw statistics into the 20 channels of one Gaussian, before L2 normalisation.
+// Channel order: utils/tf_util.py:710-719,744-747.
+__device__ __forceinline__ void finish(const Stats& s, int nrows, bool has_masked, float m_f,
+                                       float w, float (&v)[20]) {
+  const float rsw = 1.0f / sqrtf(w);           // 1/sqrt(w)        :709,714
+  const float rs2w = 1.0f / sqrtf(2.0f * w);   // 1/sqrt(2w)       :718
+  // Masked rows (index > n_eff) contribute exactly 0 to every max/min/sum (:697,:702).
+  float pmax = (s.mq - w);
+  if (has_masked) pmax = fmaxf(pmax, 0.f);
+  v[0] = pmax * rsw;
+  v[1] = (s.sq - (float)nrows * w) * rsw;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float a = s.mu_max[c], b = s.mu_min[c], d = s.sg_max[c], e = s.sg_min[c];
+    if (has_masked) { a = fmaxf(a, 0.f); b = fminf(b, 0.f); d = fmaxf(d, 0.f); e = fminf(e, 0.f); }
+    v[2 + c] = a * rsw;
+    v[5 + c] = b * rsw;
+    v[8 + c] = s.mu_sum[c] * rsw;
+    v[11 + c] = d * rs2w;
+    v[14 + c] = e * rs2w;
+    v[17 + c] = s.sg_sum[c] * rs2w;
+  }
+#pragma unroll
+  for (int c = 0; c < 20; ++c) v[c] = signed_sqrt(v[c] / m_f);   // :727-735
+}
+
+template <int DT>
+__global__ __launch_bounds__(kThreads) void mups_kernel(const float* __restrict__ points,
+                                                        const int32_t* __restrict__ n_eff, int B,
+                                                        int S, int P, void* __restrict__ out,
+                                                        int cstride, float sigma, float w) {
+  __shared__ float4 stage[kChunk][3 * kR];   // (q, d, d^2-1, -) per point, axis, grid index
+  __shared__ float red[kThreads / 64][20];
+  __shared__ float norm2[20];
+
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  const int k = t & 7, j = (t >> 3) & 7, i0 = t >> 6;
+  const int lane = t & 63, wave = t >> 6;
+  const int g0 = 64 * i0 + 8 * j + k;
+  const int g1 = g0 + 256;
+
+  for (int s = 0; s < S; ++s) {
+    const int m = n_eff[(size_t)b * S + s];
+    const size_t o0 = ((size_t)b * kG + g0) * cstride + 20 * s;
+    const size_t o1 = ((size_t)b * kG + g1) * cstride + 20 * s;
+    if (m <= 0) {   // zero-padded batch tail (test_n_est_w_experts.py:134-140): skip, do not divide by 0
+      float z[20];
+#pragma unroll
+      for (int c = 0; c < 20; ++c) z[c] = 0.f;
+      store20<DT>(out, o0, z);
+      store20<DT>(out, o1, z);
+      continue;
+    }
+    // rows 0..m are unmasked: `mask = r > n_eff` (utils/tf_util.py:693), so row m -- normally the
+    // first zero-padding row -- is counted as a point.
+    const int nrows = min(m + 1, P);
+    const bool has_masked = nrows < P;
+    const float* pts = points + ((size_t)b * S + s) * (size_t)P * 3;
+
+    Stats a0, a1;
+    a0.init();
+    a1.init();
+
+    for (int c0 = 0; c0 < nrows; c0 += kChunk) {
+      __syncthreads();
+      if (t < 3 * kChunk) {
+        const int axis = t >> 6, nl = t & 63;
+        if (c0 + nl < nrows) {
+          const float x = pts[(size_t)(c0 + nl) * 3 + axis];
+          float d[kR], e[kR], sum = 0.f;
+#pragma unroll
+          for (int i = 0; i < kR; ++i) {
+            const float mu = -0.875f + 0.25f * (float)i;      // utils/utils.py:81-87 (exact in fp32)
+            d[i] = (x - mu) / sigma;                           // utils/tf_util.py:687
+            e[i] = expf(-0.5f * d[i] * d[i]);
+            sum += e[i];
+          }
+#pragma unroll
+          for (int i = 0; i < kR; ++i)
+            stage[nl][axis * kR + i] = make_float4(e[i] / sum, d[i], d[i] * d[i] - 1.0f, 0.f);
+        }
+      }
+      __syncthreads();
+      const int cnt = min(kChunk, nrows - c0);
+      for (int nl = 0; nl < cnt; ++nl) {
+        const float4 X0 = stage[nl][i0];
+        const float4 X1 = stage[nl][i0 + 4];
+        const float4 Y = stage[nl][kR + j];
+        const float4 Z = stage[nl][2 * kR + k];
+        const float qyz = Y.x * Z.x;
+        {
+          const float d[3] = {X0.y, Y.y, Z.y};
+          const float e[3] = {X0.z, Y.z, Z.z};
+          a0.update(X0.x * qyz, d, e);
+        }
+        {
+          const float d[3] = {X1.y, Y.y, Z.y};
+          const float e[3] = {X1.z, Y.z, Z.z};
+          a1.update(X1.x * qyz, d, e);
+        }
+      }
+    }
+
+    float v0[20], v1[20];
+    const float m_f = (float)m;                    // utils/tf_util.py:722
+    finish(a0, nrows, has_masked, m_f, w, v0);
+    finish(a1, nrows, has_masked, m_f, w, v1);
+
+    // L2 normalisation over the 512 Gaussians, per channel (utils/tf_util.py:738-740)
+    float part[20];
+#pragma unroll
+    for (int c = 0; c < 20; ++c) {
+      float p = v0[c] * v0[c] + v1[c] * v1[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
+      part[c] = p;
+    }
+    __syncthreads();   // previous scale's norm2 readers are done
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 20; ++c) red[wave][c] = part[c];
+    }
+    __syncthreads();
+    if (t < 20) norm2[t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 20; ++c) {
+      const float inv = 1.0f / sqrtf(fmaxf(norm2[c], 1e-12f));
+      v0[c] *= inv;
+      v1[c] *= inv;
+    }
+    store20<DT>(out, o0, v0);
+    store20<DT>(out, o1, v1);
+  }
+
+  // zero the padding channels [20*S, cstride) so downstream GEMMs can read whole rows
+  const int pad0 = 20 * S;
+  if (pad0 < cstride) {
+    using E = Elem<DT>;
+    typename E::T* o = reinterpret_cast<typename E::T*>(out);
+    for (int c = pad0; c < cstride; ++c) {
+      o[((size_t)b * kG + g0) * cstride + c] = E::from_f32(0.f);
+      o[((size_t)b * kG + g1) * cstride + c] = E::from_f32(0.f);
+    }
+  }
+}
+
+}  // namespace
+
+int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n_eff, int B,
+                void* out, int out_dtype, int out_cstride, hipStream_t stream) {
+  if (cfg->grid_n != kR) NESTI_FAIL("nesti_mups_forward: only the 8^3 Gaussian grid is implemented");
+  if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("nesti_mups_forward: bad n_scales");
+  if (out_cstride < 20 * cfg->n_scales || (out_cstride % 4) != 0)
+    NESTI_FAIL("nesti_mups_forward: out_cstride must be >= 20*S and a multiple of 4");
+  if (B <= 0) return 0;
+  const float sigma = (float)sqrt(cfg->variance);     // np.sqrt in f64, then the f32 placeholder: test_n_est_w_experts.py:146
+  const float w = 1.0f / (float)kG;                  // utils/utils.py:89
+  dim3 grid(B), block(kThreads);
+  switch (out_dtype) {
+    case NESTI_F32:
+      hipLaunchKernelGGL(mups_kernel<NESTI_F32>, grid, block, 0, stream, points, n_eff, B,
+                         cfg->n_scales, cfg->points_per_scale, out, out_cstride, sigma, w);
+      break;
+    case NESTI_BF16:
+      hipLaunchKernelGGL(mups_kernel<NESTI_BF16>, grid, block, 0, stream, points, n_eff, B,
+                         cfg->n_scales, cfg->points_per_scale, out, out_cstride, sigma, w);
+      break;
+    case NESTI_F16:
+      hipLaunchKernelGGL(mups_kernel<NESTI_F16>, grid, block, 0, stream, points, n_eff, B,
+                         cfg->n_scales, cfg->points_per_scale, out, out_cstride, sigma, w);
+      break;
+    default:
+      NESTI_FAIL("nesti_mups_forward: unknown out_dtype");
+  }
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace nesti

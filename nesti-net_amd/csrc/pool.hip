@@ -1,0 +1,238 @@
+// Memory-bound helper kernels of the CNN towers: 3-D average / max pooling on
+// channels-last activations, the gating softmax + arg-max + routing, and the final scatter.
+#include "kernels.h"
+
+namespace nesti {
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int DT> struct Vec16;   // 16-byte vector of elements <-> floats
+template <> struct Vec16<NESTI_F32> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+  }
+};
+template <int DT> struct Vec16_16 {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void unpack(const uint4& v, float* f) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = Elem<DT>::to_f32((uint16_t)(w[i] & 0xffffu));
+      f[2 * i + 1] = Elem<DT>::to_f32((uint16_t)(w[i] >> 16));
+    }
+  }
+  static __device__ __forceinline__ uint4 pack(const float* f) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      w[i] = (uint32_t)Elem<DT>::from_f32(f[2 * i]) | ((uint32_t)Elem<DT>::from_f32(f[2 * i + 1]) << 16);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+template <> struct Vec16<NESTI_BF16> : Vec16_16<NESTI_BF16> {};
+template <> struct Vec16<NESTI_F16> : Vec16_16<NESTI_F16> {};
+
+// tf.nn.avg_pool3d k^3 stride 1 SAME (utils/tf_util.py:450-454): mean over the taps inside the
+// volume; window offsets follow TF SAME (low pad = (k-1)/2).
+template <int DT>
+__global__ __launch_bounds__(kThreads) void avgpool_kernel(const PoolParams p) {
+  using V = Vec16<DT>;
+  constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
+  int npts = p.npoints;
+  if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
+  const int log2S = p.log2S, S = 1 << log2S, log2V = 3 * log2S;
+  const int vecs = p.C / V::N;
+  const long long total = ((long long)npts << log2V) * vecs;
+  const int lo = (p.k - 1) / 2;
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+  unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int cv = (int)(i % vecs);
+    const long long row = i / vecs;
+    const long long pt = row >> log2V;
+    const int vox = (int)(row & ((1 << log2V) - 1));
+    const int z = vox >> (2 * log2S), y = (vox >> log2S) & (S - 1), x = vox & (S - 1);
+    const long long spt = p.point_index ? (long long)p.point_index[pt] : pt;
+    float acc[V::N];
+#pragma unroll
+    for (int e = 0; e < V::N; ++e) acc[e] = 0.f;
+    int cnt = 0;
+    for (int a = 0; a < p.k; ++a) {
+      const int zz = z + a - lo;
+      if ((unsigned)zz >= (unsigned)S) continue;
+      for (int b = 0; b < p.k; ++b) {
+        const int yy = y + b - lo;
+        if ((unsigned)yy >= (unsigned)S) continue;
+        for (int c = 0; c < p.k; ++c) {
+          const int xx = x + c - lo;
+          if ((unsigned)xx >= (unsigned)S) continue;
+          const long long srow = (spt << log2V) + (((zz << log2S) + yy) << log2S) + xx;
+          const uint4 v = *reinterpret_cast<const uint4*>(in_b + (srow * p.in_cstride + p.in_coff) * kEsz + cv * 16);
+          float f[V::N];
+          V::unpack(v, f);
+#pragma unroll
+          for (int e = 0; e < V::N; ++e) acc[e] += f[e];
+          ++cnt;
+        }
+      }
+    }
+    const float cf = (float)cnt;
+#pragma unroll
+    for (int e = 0; e < V::N; ++e) acc[e] = acc[e] / cf;
+    *reinterpret_cast<uint4*>(out_b + (row * p.out_cstride + p.out_coff) * kEsz + cv * 16) = V::pack(acc);
+  }
+}
+
+// tf.nn.max_pool3d 2^3 stride 2 SAME on an even volume (utils/tf_util.py:424-428)
+template <int DT>
+__global__ __launch_bounds__(kThreads) void maxpool2_kernel(const PoolParams p) {
+  using V = Vec16<DT>;
+  constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
+  int npts = p.npoints;
+  if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
+  const int log2S = p.log2S, log2V = 3 * log2S;
+  const int log2So = log2S - 1, So = 1 << log2So, log2Vo = 3 * log2So;
+  const int vecs = p.C / V::N;
+  const long long total = ((long long)npts << log2Vo) * vecs;
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+  unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
+    const int cv = (int)(i % vecs);
+    const long long orow = i / vecs;
+    const long long pt = orow >> log2Vo;
+    const int vox = (int)(orow & ((1 << log2Vo) - 1));
+    const int z = vox >> (2 * log2So), y = (vox >> log2So) & (So - 1), x = vox & (So - 1);
+    float m[V::N];
+#pragma unroll
+    for (int e = 0; e < V::N; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int zz = 2 * z + (a >> 2), yy = 2 * y + ((a >> 1) & 1), xx = 2 * x + (a & 1);
+      const long long srow = (pt << log2V) + (((zz << log2S) + yy) << log2S) + xx;
+      const uint4 v = *reinterpret_cast<const uint4*>(in_b + (srow * p.in_cstride + p.in_coff) * kEsz + cv * 16);
+      float f[V::N];
+      V::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < V::N; ++e) m[e] = fmaxf(m[e], f[e]);
+    }
+    *reinterpret_cast<uint4*>(out_b + (orow * p.out_cstride + p.out_coff) * kEsz + cv * 16) = V::pack(m);
+  }
+}
+
+// softmax (models/experts_n_est.py:177) + np.argmax first-index tie-break
+// (test_n_est_w_experts.py:150) + optional routing lists for top-1 execution.
+__global__ void gate_finish_kernel(const float* __restrict__ logits, int lstride, int B, int E,
+                                   float* __restrict__ probs, int32_t* __restrict__ expert,
+                                   int32_t* __restrict__ counts, int32_t* __restrict__ lists) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float l[NESTI_MAX_EXPERTS], mx = -INFINITY;
+  for (int e = 0; e < E; ++e) { l[e] = logits[(size_t)b * lstride + e]; mx = fmaxf(mx, l[e]); }
+  float sum = 0.f;
+  for (int e = 0; e < E; ++e) { l[e] = expf(l[e] - mx); sum += l[e]; }
+  int best = 0;
+  float pb = -1.f;
+  for (int e = 0; e < E; ++e) {
+    const float pr = l[e] / sum;
+    if (probs) probs[(size_t)b * E + e] = pr;
+    if (pr > pb) { pb = pr; best = e; }
+  }
+  if (expert) expert[b] = best;
+  if (counts) {
+    const int pos = atomicAdd(&counts[best], 1);
+    lists[(size_t)best * B + pos] = b;
+  }
+}
+
+__global__ void route_kernel(const int32_t* __restrict__ expert, int B, int E,
+                             int32_t* __restrict__ counts, int32_t* __restrict__ lists) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int e = expert[b];
+  if (e < 0 || e >= E) return;
+  const int pos = atomicAdd(&counts[e], 1);
+  lists[(size_t)e * B + pos] = b;
+}
+
+__global__ void scatter3_kernel(const float* __restrict__ src, int sstride, const int32_t* __restrict__ index,
+                                const int32_t* __restrict__ count_ptr, int count_cap, float* __restrict__ out) {
+  int n = count_cap;
+  if (count_ptr) n = min(n, *count_ptr);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const long long d = index ? index[j] : j;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[d * 3 + c] = src[(size_t)j * sstride + c];
+}
+
+int grid_for(long long work) {
+  long long g = (work + kThreads - 1) / kThreads;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+int launch_avgpool(const PoolParams& p, int dtype, hipStream_t stream) {
+  if (p.npoints <= 0) return 0;
+  const int n = (dtype == NESTI_F32) ? 4 : 8;
+  if (p.C % n) NESTI_FAIL("avgpool: C must be a multiple of the 16-byte vector");
+  const long long work = ((long long)p.npoints << (3 * p.log2S)) * (p.C / n);
+  dim3 grid(grid_for(work)), block(kThreads);
+  if (dtype == NESTI_F32) hipLaunchKernelGGL(avgpool_kernel<NESTI_F32>, grid, block, 0, stream, p);
+  else if (dtype == NESTI_BF16) hipLaunchKernelGGL(avgpool_kernel<NESTI_BF16>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(avgpool_kernel<NESTI_F16>, grid, block, 0, stream, p);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_maxpool2(const PoolParams& p, int dtype, hipStream_t stream) {
+  if (p.npoints <= 0) return 0;
+  if (p.log2S < 1) NESTI_FAIL("maxpool2: input volume must be >= 2^3");
+  const int n = (dtype == NESTI_F32) ? 4 : 8;
+  if (p.C % n) NESTI_FAIL("maxpool2: C must be a multiple of the 16-byte vector");
+  const long long work = ((long long)p.npoints << (3 * (p.log2S - 1))) * (p.C / n);
+  dim3 grid(grid_for(work)), block(kThreads);
+  if (dtype == NESTI_F32) hipLaunchKernelGGL(maxpool2_kernel<NESTI_F32>, grid, block, 0, stream, p);
+  else if (dtype == NESTI_BF16) hipLaunchKernelGGL(maxpool2_kernel<NESTI_BF16>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(maxpool2_kernel<NESTI_F16>, grid, block, 0, stream, p);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gate_finish(const float* logits, int lstride, int B, int E, float* probs, int32_t* expert,
+                       int32_t* counts, int32_t* lists, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (E > NESTI_MAX_EXPERTS) NESTI_FAIL("gate_finish: too many experts");
+  if (counts) NESTI_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * E, stream));
+  hipLaunchKernelGGL(gate_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, E,
+                     probs, expert, counts, lists);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_route(const int32_t* expert, int B, int E, int32_t* counts, int32_t* lists, hipStream_t stream) {
+  if (B <= 0) return 0;
+  NESTI_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * E, stream));
+  hipLaunchKernelGGL(route_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, expert, B, E, counts, lists);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_scatter3(const float* src, int sstride, const int32_t* index, const int32_t* count_ptr,
+                    int count_cap, float* out, hipStream_t stream) {
+  if (count_cap <= 0) return 0;
+  hipLaunchKernelGGL(scatter3_kernel, dim3((count_cap + 255) / 256), dim3(256), 0, stream, src, sstride,
+                     index, count_ptr, count_cap, out);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace nesti

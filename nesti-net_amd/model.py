@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's model seam.
+
+The reference selects a model module by name and calls
+``placeholder_inputs`` / ``get_model`` on it (``test_n_est_w_experts.py:60-61,74-80``,
+``models/experts_n_est.py:12-108``), then executes one ``sess.run`` per batch
+(``test_n_est_w_experts.py:148``).  :class:`NestiNet` plays both roles: constructing
+it is "build graph + restore checkpoint", calling it is ``sess.run``.
+All compute happens in ``libnesti_hip.so``.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import DTYPES, NestiConfig
+
+_TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def get_3d_grid_gmm(subdivisions=(8, 8, 8), variance=0.0156):
+    """``utils/utils.py:70-95`` without sklearn: returns (weights_, means_, sigma) as
+    float32 arrays, sigma = sqrt(covariances_) as fed at ``test_n_est_w_experts.py:146``."""
+    n = int(subdivisions[0])
+    if tuple(subdivisions) != (n, n, n):
+        raise ValueError("only cubic grids are supported")
+    G = n ** 3
+    w = np.empty(G, np.float32)
+    mu = np.empty((G, 3), np.float32)
+    sg = np.empty((G, 3), np.float32)
+    lib = _lib.load()
+    _lib.check(lib.nesti_gmm_grid(n, float(variance), _lib.ptr(w), _lib.ptr(mu), _lib.ptr(sg)), "nesti_gmm_grid")
+    return w, mu, sg
+
+
+def mups_forward(cfg: NestiConfig, points, n_eff, out_dtype="f32", out_cstride=None, stream=None):
+    """``get_3dmfv_n_est`` per scale + MuPS assembly (``utils/tf_util.py:655-753``,
+    ``models/experts_n_est.py:66-76``).
+
+    points [B, S*P, 3] float32 cuda, n_eff [B, S] (any integer/float dtype, like the
+    uint16 placeholder ``models/experts_n_est.py:35``) -> [B, R, R, R, cstride]."""
+    lib = _lib.load()
+    if not points.is_cuda:
+        raise _lib.NestiError("mups_forward needs CUDA/HIP tensors; there is no CPU path")
+    B = points.shape[0]
+    S, P, R = cfg.n_scales, cfg.num_point, cfg.n_gaussians
+    if tuple(points.shape) != (B, S * P, 3):
+        raise ValueError("points must be [B, %d, 3], got %s" % (S * P, tuple(points.shape)))
+    points = points.contiguous().float()
+    n_eff_i = n_eff.to(device=points.device, dtype=torch.int32).contiguous()
+    if tuple(n_eff_i.shape) != (B, S):
+        raise ValueError("n_eff must be [B, %d]" % S)
+    cs = out_cstride or 20 * S
+    out = torch.empty((B, R, R, R, cs), dtype=_TORCH_DT[out_dtype], device=points.device)
+    c = cfg.to_c()
+    _lib.check(lib.nesti_mups_forward(ctypes.byref(c), _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(out),
+                                      DTYPES[out_dtype], cs, _lib.stream_ptr(stream)), "nesti_mups_forward")
+    return out
+
+
+class NestiNet:
+    """The MoE normal estimator on one GPU.
+
+    ``weights``: dict name -> float32 ndarray in TF variable layout (see
+    :mod:`.weights`).  ``dtype``: 'bf16' / 'f16' (MFMA 32x32x16, fp32 accumulate) or
+    'f32' (exact-fp32 MFMA; the parity mode)."""
+
+    def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", max_batch=1024):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.NestiError("NestiNet needs a GPU: libnesti_hip.so has no CPU path")
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self._c = cfg.to_c()
+        self._handle = ctypes.c_void_p()
+        names = list(weights.keys())
+        self._keep = [np.ascontiguousarray(weights[k], dtype=np.float32) for k in names]
+        arr = (_lib.CTensor * len(names))()
+        for i, (k, a) in enumerate(zip(names, self._keep)):
+            arr[i].name = k.encode()
+            arr[i].data = a.ctypes.data
+            arr[i].ndim = a.ndim
+            for d in range(a.ndim):
+                arr[i].dims[d] = a.shape[d]
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_model_create(ctypes.byref(self._c), arr, len(names), DTYPES[dtype],
+                                                   ctypes.byref(self._handle)), "nesti_model_create")
+        self._keep = None
+        self.mups_cstride = self.lib.nesti_model_mups_cstride(self._handle)
+        self._ws = None
+        self._ws_batch = 0
+        self.reserve(max_batch)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.value:
+            self.lib.nesti_model_destroy(h)
+            self._handle = ctypes.c_void_p()
+
+    # -- workspace -------------------------------------------------------------------------
+    def reserve(self, batch):
+        if batch > self._ws_batch:
+            nbytes = self.lib.nesti_workspace_bytes(self._handle, int(batch))
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_batch = int(batch)
+        return self._ws
+
+    # -- pieces (tests and the reference-shaped API) ---------------------------------------
+    def mups(self, points, n_eff, stream=None):
+        """MuPS in the model's internal layout [B, R^3... , cstride] / dtype."""
+        return mups_forward(self.cfg, points, n_eff, out_dtype=self.dtype, out_cstride=self.mups_cstride, stream=stream)
+
+    def gate(self, mups, stream=None):
+        """``scale_manager_net`` + arg-max -> (probs [B,E] f32, expert [B] int32)."""
+        B = mups.shape[0]
+        ws = self.reserve(B)
+        E = self.cfg.n_experts
+        probs = torch.empty((B, E), dtype=torch.float32, device=self.device)
+        expert = torch.empty((B,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.nesti_gate_forward(self._handle, _lib.ptr(mups), B, _lib.ptr(ws), ws.numel(),
+                                               _lib.ptr(probs), _lib.ptr(expert), _lib.stream_ptr(stream)),
+                   "nesti_gate_forward")
+        return probs, expert
+
+    def experts(self, mups, expert=None, stream=None):
+        """``normal_est_net`` x E.  expert=None -> n_est [E,B,3] (reference behaviour);
+        expert=[B] int32 -> top-1 routed normals [B,3]."""
+        B = mups.shape[0]
+        ws = self.reserve(B)
+        E = self.cfg.n_experts
+        if expert is None:
+            out = torch.empty((E, B, 3), dtype=torch.float32, device=self.device)
+            ex = None
+        else:
+            out = torch.zeros((B, 3), dtype=torch.float32, device=self.device)
+            ex = expert.to(device=self.device, dtype=torch.int32).contiguous()
+        _lib.check(self.lib.nesti_experts_forward(self._handle, _lib.ptr(mups), _lib.ptr(ex), B, _lib.ptr(ws), ws.numel(),
+                                                  _lib.ptr(out), _lib.stream_ptr(stream)), "nesti_experts_forward")
+        return out
+
+    # -- the sess.run equivalent -----------------------------------------------------------
+    def forward(self, points, n_eff, out=None, stream=None):
+        """points [B,S*P,3] f32 cuda, n_eff [B,S] -> (normals [B,3] f32, expert [B] int32, probs [B,E] f32).
+
+        Equals ``n_est[argmax(experts_prob), range(B)]``, ``argmax`` and
+        ``transpose(experts_prob)`` of ``test_n_est_w_experts.py:148-152``."""
+        B = points.shape[0]
+        ws = self.reserve(B)
+        E = self.cfg.n_experts
+        points = points.contiguous()
+        if points.dtype != torch.float32:
+            points = points.float()
+        n_eff_i = n_eff if (n_eff.dtype == torch.int32 and n_eff.is_contiguous()) else n_eff.to(torch.int32).contiguous()
+        if out is None:
+            normals = torch.empty((B, 3), dtype=torch.float32, device=self.device)
+            expert = torch.empty((B,), dtype=torch.int32, device=self.device)
+            probs = torch.empty((B, E), dtype=torch.float32, device=self.device)
+        else:
+            normals, expert, probs = out
+        _lib.check(self.lib.nesti_forward(self._handle, _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(ws), ws.numel(),
+                                          _lib.ptr(normals), _lib.ptr(expert), _lib.ptr(probs),
+                                          _lib.stream_ptr(stream)), "nesti_forward")
+        return normals, expert, probs
+
+    __call__ = forward
+
+
+# ---- reference-shaped free functions (models/experts_n_est.py:12-108) ---------------------
+def placeholder_inputs(batch_size, n_points, gmm, radius, device="cuda:0"):
+    """Same tuple as ``models/experts_n_est.py:12-37``, as pre-allocated device tensors."""
+    w, mu, sg = gmm
+    n_rads = len(radius)
+    dev = torch.device(device)
+    return (torch.zeros((batch_size, n_points * n_rads, 3), dtype=torch.float32, device=dev),
+            torch.zeros((batch_size, 3), dtype=torch.float32, device=dev),
+            torch.as_tensor(w, device=dev), torch.as_tensor(mu, device=dev), torch.as_tensor(sg, device=dev),
+            torch.zeros((batch_size, n_rads), dtype=torch.int32, device=dev))
+
+
+def get_model(net: NestiNet, points, original_n_points):
+    """``models/experts_n_est.py:40-108`` return contract:
+    (experts_prob [E,B], n_est [E,B,3], MuPS [B,R,R,R,20*S])."""
+    mups = net.mups(points, original_n_points)
+    probs, _ = net.gate(mups)
+    n_est = net.experts(mups, None)
+    S = net.cfg.n_scales
+    return probs.t().contiguous(), n_est, mups[..., :20 * S].float()

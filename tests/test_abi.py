@@ -1,0 +1,92 @@
+"""CPU-only checks of the boundary: the C-ABI library loads without a GPU and exports every
+symbol include/nesti_hip.h declares; host-only entry points behave."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+from conftest import REPO
+
+
+def _header_symbols():
+    src = open(os.path.join(REPO, "include", "nesti_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nesti_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import _lib
+    lib = _lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), "missing export %s" % s
+        assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_gmm_grid_matches_oracle():
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd.model import get_3d_grid_gmm
+    from oracle import mups_ref
+    w, mu, sg = get_3d_grid_gmm((8, 8, 8), 0.0156)
+    ow, omu, osg = mups_ref.grid_gmm(8, 0.0156)
+    assert np.array_equal(w, ow.astype(np.float32))
+    assert np.array_equal(mu, omu.astype(np.float32))
+    assert np.array_equal(sg, osg.astype(np.float32))
+    w3, mu3, _ = get_3d_grid_gmm((3, 3, 3), 0.04)
+    o3 = mups_ref.grid_gmm(3, 0.04)
+    assert np.array_equal(mu3, o3[1].astype(np.float32)) and np.allclose(w3, 1 / 27.0)
+
+
+def test_describe_matches_reference_graph():
+    """Variable names/shapes follow models/experts_n_est.py (scopes, Python-2 filter counts)."""
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import NestiConfig
+    d = weights.describe(NestiConfig())
+    assert d["inception1gating_conv_conv1/weights"] == (1, 1, 1, 60, 128)
+    assert d["inception3gating_conv_conv3/weights"] == (5, 5, 5, 256, 128)
+    assert d["inception8gating_conv_conv2/weights"] == (1, 1, 1, 512, 256)
+    assert d["inception8gating_conv_conv3/weights"] == (2, 2, 2, 512, 256)
+    assert d["fc1noise/weights"] == (1536, 1024) and d["fc4noise/weights"] == (128, 7)
+    assert "fc4noise/bn/beta" not in d and "fc3noise/bn/beta" in d
+    assert d["inception1Expert_0_conv1/weights"] == (1, 1, 1, 20, 128)
+    assert d["inception1Expert_6_conv1/weights"] == (1, 1, 1, 60, 42)        # 128/3 under py2 (experts_n_est.py:254)
+    assert d["inception1Expert_6_conv2/weights"] == (3, 3, 3, 42, 21)
+    assert d["inception2Expert_6_conv1/weights"] == (1, 1, 1, 126, 256)
+    assert d["inception6Expert_3_conv3/weights"] == (4, 4, 4, 512, 256)
+    assert d["fc4Expert_5/weights"] == (64, 3)
+    n_params = sum(int(np.prod(v)) for k, v in d.items() if k.endswith("/weights"))
+    assert abs(n_params - 178.3e6) < 0.1e6
+
+
+def test_config_expert_dict_and_errors():
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import _lib
+    from nesti_net_amd.config import NestiConfig
+    cfg = NestiConfig()
+    c = cfg.to_c()
+    assert list(c.expert_scale_lo)[:7] == [0, 0, 1, 1, 2, 2, 0] and list(c.expert_scale_cnt)[:7] == [1, 1, 1, 1, 1, 1, 3]
+    assert NestiConfig(expert_dict=None).default_expert_dict() == {0: [0], 1: [0], 2: [1], 3: [1], 4: [2], 5: [2],
+                                                                    6: [0, 1, 2]}
+    lib = _lib.load()
+    bad = NestiConfig(n_gaussians=3).to_c()
+    n = ctypes.c_int(0)
+    assert lib.nesti_model_describe(ctypes.byref(bad), ctypes.byref(n), None, 0) != 0
+    assert b"8^3" in lib.nesti_last_error()
+
+
+def test_weight_container_roundtrip(tmp_path):
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import NestiConfig
+    cfg = NestiConfig()
+    W = {"a/weights": np.arange(24, dtype=np.float32).reshape(1, 1, 1, 4, 6), "a/biases": np.ones(6, np.float32)}
+    p = str(tmp_path / "w.nstw")
+    weights.save(p, W, cfg)
+    W2, cfg2 = weights.load(p)
+    assert list(W2) == list(W) and all(np.array_equal(W[k], W2[k]) for k in W)
+    assert cfg2 == cfg

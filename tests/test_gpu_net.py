@@ -1,0 +1,145 @@
+"""Gating + expert towers (MFMA implicit-GEMM conv stack) through the C-ABI vs the torch-CPU
+fp64 oracle (oracle/net_ref.py) with seeded synthetic weights.
+
+Tolerances (north_star): expert arg-max bit-exact, normals within 1e-5 cosine -- asserted in
+the exact-fp32 mode ('f32': v_mfma_f32_32x32x2_f32).  The bf16/f16 production modes are
+checked against looser, stated bounds."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_patch_files, load_golden_patches
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL_F32 = 1e-5
+PROB_TOL_F32 = 2e-5
+
+
+def _cos(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+@pytest.fixture(scope="module")
+def setup(gpu_device):
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd import weights
+    cfg = NestiConfig()
+    W = weights.synthetic_weights(cfg)
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid100k" in p][0])
+    g2 = load_golden_patches([p for p in golden_patch_files() if "ellipsoid20k" in p][0])
+    pts = np.concatenate([g["points"][:10], g2["points"][:6]])
+    n_eff = np.concatenate([g["n_eff"][:10], g2["n_eff"][:6]])
+    return cfg, W, pts, n_eff
+
+
+@pytest.fixture(scope="module")
+def oracle_out(setup):
+    from oracle import mups_ref, net_ref
+    cfg, W, pts, n_eff = setup
+    mups = mups_ref.mups_assemble(pts, n_eff, 3)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    full = net_ref.moe_forward(mups[:6], W, dtype=torch.float64, top1_only=False)      # reference behaviour
+    top1 = net_ref.moe_forward(mups, W, dtype=torch.float64, top1_only=True)
+    return mups, full, top1
+
+
+@pytest.fixture(scope="module")
+def net_f32(setup, gpu_device):
+    from nesti_net_amd.model import NestiNet
+    cfg, W, _, _ = setup
+    return NestiNet(cfg, W, dtype="f32", device=gpu_device, max_batch=16)
+
+
+def test_f32_gate_and_routing_match_oracle(setup, oracle_out, net_f32, gpu_device):
+    cfg, W, pts, n_eff = setup
+    mups_o, full, top1 = oracle_out
+    p = torch.as_tensor(pts, device=gpu_device)
+    n = torch.as_tensor(n_eff, device=gpu_device)
+    mups = net_f32.mups(p, n)
+    assert np.abs(mups[..., :60].cpu().numpy() - mups_o).max() < 2e-5
+    probs, expert = net_f32.gate(mups)
+    torch.cuda.synchronize()
+    pe = np.abs(probs.cpu().numpy() - top1["probs"].numpy()).max()
+    print("gate prob max abs err (f32):", pe, "experts:", expert.cpu().numpy())
+    assert np.array_equal(expert.cpu().numpy(), top1["expert"].numpy())      # bit-exact arg-max
+    assert pe < PROB_TOL_F32
+
+
+def test_f32_all_experts_match_oracle(setup, oracle_out, net_f32, gpu_device):
+    """Reference behaviour: every expert on every point -> n_est [E,B,3]."""
+    cfg, W, pts, n_eff = setup
+    _, full, _ = oracle_out
+    mups = net_f32.mups(torch.as_tensor(pts[:6], device=gpu_device), torch.as_tensor(n_eff[:6], device=gpu_device))
+    n_est = net_f32.experts(mups, None).cpu().numpy()
+    ref = full["n_est"].numpy()
+    c = _cos(n_est, ref)
+    print("all-experts min cosine (f32):", c.min(), "max abs err", np.abs(n_est - ref).max())
+    assert n_est.shape == (7, 6, 3)
+    assert np.all(1 - c < COS_TOL_F32)
+    assert np.abs(n_est - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_f32_forward_top1_matches_oracle_and_all_experts(setup, oracle_out, net_f32, gpu_device):
+    cfg, W, pts, n_eff = setup
+    _, full, top1 = oracle_out
+    p = torch.as_tensor(pts, device=gpu_device)
+    n = torch.as_tensor(n_eff, device=gpu_device)
+    normals, expert, probs = net_f32(p, n)
+    torch.cuda.synchronize()
+    assert np.array_equal(expert.cpu().numpy(), top1["expert"].numpy())
+    c = _cos(normals.cpu().numpy(), top1["normals"].numpy())
+    print("top-1 min cosine (f32):", c.min())
+    assert np.all(1 - c < COS_TOL_F32)
+    # top-1 routing is output-identical to evaluate-all-then-select (test_n_est_w_experts.py:148-152)
+    mups = net_f32.mups(p[:6], n[:6])
+    n_est = net_f32.experts(mups, None)
+    sel = n_est[expert[:6].long(), torch.arange(6, device=gpu_device)]
+    assert torch.equal(sel, normals[:6])
+    # explicit expert assignment path
+    routed = net_f32.experts(net_f32.mups(p, n), expert)
+    assert torch.equal(routed, normals)
+
+
+@pytest.mark.parametrize("dtype,cos_tol,prob_tol", [("bf16", 2e-3, 5e-2), ("f16", 5e-5, 1e-2)])
+def test_16bit_modes_close_to_oracle(setup, oracle_out, gpu_device, dtype, cos_tol, prob_tol):
+    from nesti_net_amd.model import NestiNet
+    cfg, W, pts, n_eff = setup
+    _, full, top1 = oracle_out
+    net = NestiNet(cfg, W, dtype=dtype, device=gpu_device, max_batch=16)
+    p = torch.as_tensor(pts, device=gpu_device)
+    n = torch.as_tensor(n_eff, device=gpu_device)
+    normals, expert, probs = net(p, n)
+    torch.cuda.synchronize()
+    pr = probs.cpu().numpy()
+    pe = np.abs(pr - top1["probs"].numpy()).max()
+    ex_ref = top1["expert"].numpy()
+    agree = expert.cpu().numpy() == ex_ref
+    # a flipped arg-max is only acceptable where the oracle's top-2 margin is inside the error bound
+    srt = np.sort(top1["probs"].numpy(), axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    print(dtype, "prob err", pe, "argmax agree", agree.mean(), "min margin", margin.min())
+    assert pe < prob_tol
+    assert np.all(agree | (margin < 2 * prob_tol))
+    mups = net.mups(p[:6], n[:6])
+    n_est = net.experts(mups, None).cpu().numpy()
+    c = _cos(n_est, full["n_est"].numpy())
+    print(dtype, "all-experts min cosine:", c.min())
+    assert np.all(1 - c < cos_tol)
+
+
+def test_ragged_batches_and_padding_rows(setup, net_f32, gpu_device):
+    """Batch sizes that are not multiples of any tile, B=1, and the reference's zero-padded tail
+    (n_eff = 0 rows, test_n_est_w_experts.py:134-140): finite outputs, real rows unaffected."""
+    cfg, W, pts, n_eff = setup
+    p = torch.as_tensor(pts, device=gpu_device)
+    n = torch.as_tensor(n_eff, device=gpu_device)
+    full, ex_full, pr_full = net_f32(p[:13], n[:13])
+    one, ex_one, _ = net_f32(p[4:5], n[4:5])
+    assert torch.equal(one[0], full[4]) and ex_one[0] == ex_full[4]
+    pad_p = torch.cat([p[:5], torch.zeros_like(p[:3])])
+    pad_n = torch.cat([n[:5], torch.zeros_like(n[:3])])
+    out, ex, pr = net_f32(pad_p, pad_n)
+    assert torch.isfinite(out).all() and torch.isfinite(pr).all()
+    assert torch.equal(out[:5], full[:5])

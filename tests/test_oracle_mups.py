@@ -1,0 +1,89 @@
+"""Known-answer and cross-implementation checks for oracle/mups_ref.py (CPU only).
+
+The TF arithmetic itself cannot be executed here (parity unpinned at the TF boundary), so
+the literal transcription of utils/tf_util.py:655-753 is pinned against (i) an independent
+separable derivation and (ii) hand-computed cases."""
+import numpy as np
+
+from oracle import mups_ref as M
+
+
+def test_grid_gmm_layout():
+    w, mu, sg = M.grid_gmm(8, 0.0156)
+    assert w.shape == (512,) and mu.shape == (512, 3)
+    assert np.allclose(w, 1 / 512.0)
+    assert np.allclose(mu[0], [-0.875] * 3) and np.allclose(mu[1], [-0.875, -0.875, -0.625])   # z fastest
+    assert np.allclose(mu[64], [-0.625, -0.875, -0.875])                                          # x slowest
+    assert np.allclose(sg, np.sqrt(0.0156))
+
+
+def _patch(rng, B, P, n_eff):
+    pts = rng.uniform(-1, 1, (B, P, 3)) * 0.6
+    for b in range(B):
+        pts[b, n_eff[b]:] = 0
+    return pts
+
+
+def test_literal_equals_separable():
+    rng = np.random.RandomState(0)
+    w, mu, sg = M.grid_gmm()
+    n_eff = np.array([512, 20, 5, 511, 1])
+    pts = _patch(rng, 5, 512, n_eff)
+    a = M.mups_literal(pts, w, mu, sg, n_eff)
+    b = M.mups_separable(pts, w, mu, sg, n_eff)
+    assert np.abs(a - b).max() < 1e-13
+    # per-channel unit L2 norm over the 512 Gaussians (utils/tf_util.py:738-740)
+    v = a.reshape(5, 20, 512)
+    assert np.allclose((v * v).sum(-1), 1.0, atol=1e-9)
+
+
+def test_mask_off_by_one_row_is_counted():
+    """`mask = r > n_eff` (utils/tf_util.py:693): row n_eff is NOT masked."""
+    rng = np.random.RandomState(1)
+    w, mu, sg = M.grid_gmm()
+    n_eff = np.array([10])
+    pts = _patch(rng, 1, 64, n_eff)
+    base = M.mups_literal(pts, w, mu, sg, n_eff)
+    moved = pts.copy()
+    moved[0, 10] = [0.3, -0.2, 0.1]          # row n_eff: counted
+    assert np.abs(M.mups_literal(moved, w, mu, sg, n_eff) - base).max() > 1e-3
+    moved = pts.copy()
+    moved[0, 11] = [0.3, -0.2, 0.1]          # row n_eff+1: masked
+    assert np.abs(M.mups_literal(moved, w, mu, sg, n_eff) - base).max() == 0
+
+
+def test_single_point_known_answer():
+    """One point exactly on a Gaussian centre, n_eff = P = 1 (no masked rows, no extra row)."""
+    w, mu, sg = M.grid_gmm()
+    pts = mu[100][None, None, :].copy()
+    fv = M.mups_literal(pts, w, mu, sg, np.array([1])).reshape(20, 512)
+    # pi_max == pi_sum for a single row; largest at the occupied Gaussian
+    assert np.allclose(fv[0], fv[1])
+    assert np.argmax(fv[0]) == 100
+    # d_mu at the occupied Gaussian is 0 (x - mu = 0)
+    assert np.allclose(fv[2:11, 100], 0)
+    # d_sigma at the occupied Gaussian: Q*(0-1) < 0
+    assert np.all(fv[11:20, 100] < 0)
+
+
+def test_assemble_layout():
+    rng = np.random.RandomState(2)
+    S, P = 3, 32
+    n_eff = np.array([[32, 7, 20], [3, 32, 31]])
+    pts = rng.uniform(-0.5, 0.5, (2, S * P, 3))
+    out = M.mups_assemble(pts, n_eff, S)
+    assert out.shape == (2, 8, 8, 8, 60)
+    w, mu, sg = M.grid_gmm()
+    fv1 = M.mups_literal(pts[:, P:2 * P], w, mu, sg, n_eff[:, 1]).reshape(2, 20, 8, 8, 8)
+    # channel 20*s + c at grid position (x,y,z)  (models/experts_n_est.py:71-76)
+    assert np.array_equal(out[1, 2, 5, 7, 20 + 4], fv1[1, 4, 2, 5, 7])
+
+
+def test_fp32_close_to_fp64():
+    rng = np.random.RandomState(3)
+    w, mu, sg = M.grid_gmm()
+    n_eff = np.array([300, 40])
+    pts = _patch(rng, 2, 512, n_eff)
+    a = M.mups_literal(pts, w, mu, sg, n_eff)
+    b = M.mups_literal(pts.astype(np.float32), w, mu, sg, n_eff, dtype=np.float32)
+    assert np.abs(a - b).max() < 5e-6
