@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: normals/sec on synthetic 100k-point clouds (BASELINE.json metric).
+
+A step = one pass of the whole hot path (search-grid build -> multi-scale ball query -> MuPS ->
+gating net -> top-1 expert net -> normals) over one batch of synthetic clouds that are already
+resident in HBM: at N GPUs the batch is N clouds of --points points, each cloud's query rows
+block-sharded over all N ranks and re-assembled with one RCCL all-gather per cloud, so every
+rank processes --points queries per step whatever N is (weak scaling, real collective).
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 2 --warmup 1
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import nesti_net_amd  # noqa: E402,F401
+from nesti_net_amd import _lib, synth, weights  # noqa: E402
+from nesti_net_amd import dist as ndist  # noqa: E402
+from nesti_net_amd.config import NestiConfig  # noqa: E402
+from nesti_net_amd.pipeline import NormalEstimator  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
+
+
+def make_clouds(n_clouds, n_points):
+    """Cloud i: shape and PCPNet noise level cycle with i (BASELINE config 3); cloud 0 is the
+    no-noise ellipsoid the survey measured."""
+    shapes = ("ellipsoid", "sphere", "torus", "box")
+    out = []
+    for i in range(n_clouds):
+        pts, nrm = synth.make_cloud(shapes[i % 4], n=n_points, seed=1234 + i, noise=synth.PCPNET_NOISE[i % 4])
+        out.append((pts, nrm))
+    return out
+
+
+def rms_angle_deg(pred, gt):
+    """Unoriented RMS angle error in degrees (utils/evaluate.py:139-147)."""
+    pred = pred / np.maximum(np.linalg.norm(pred, axis=1, keepdims=True), 1e-12)
+    c = np.clip(np.abs((pred * gt).sum(1)), 0, 1)
+    return float(np.sqrt(np.mean(np.degrees(np.arccos(c)) ** 2)))
+
+
+def cpu_baseline(cfg, W, pts):
+    """The oracle (numpy/scipy/torch-CPU restatement of the reference) timed on this host on a
+    bounded sample of the same workload; per-stage seconds per query are summed."""
+    from oracle import mups_ref, net_ref, patches_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n_patch, n_mups, n_net = 2048, 32, 128
+    tree = patches_ref.build_tree(pts)
+    _, r_abs = patches_ref.patch_radii(pts, cfg.patch_radius)
+    t = time.time()
+    points, n_eff, _, _ = patches_ref.extract_patches(pts, np.arange(n_patch), r_abs, cfg.num_point, 3627473, tree)
+    t_patch = (time.time() - t) / n_patch
+    t = time.time()
+    mups = mups_ref.mups_assemble(points[:n_mups], n_eff[:n_mups], cfg.n_scales, dtype=np.float32)
+    t_mups = (time.time() - t) / n_mups
+    mups = np.concatenate([mups] * ((n_net + n_mups - 1) // n_mups))[:n_net]
+    t = time.time()
+    net_ref.moe_forward(mups, W, dtype=torch.float32, top1_only=True)
+    t_net = (time.time() - t) / n_net
+    per = t_patch + t_mups + t_net
+    return {"value": 1.0 / per, "unit": "normals/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/: scipy ball query %d queries (1 thread) %.2f ms/q + numpy MuPS fp32 %d queries %.1f ms/q + "
+                      "torch-CPU fp32 gate+top-1 expert %d queries (%d threads) %.1f ms/q, same 100k cloud; the "
+                      "reference itself evaluates all 7 experts (about 2.9x the CNN work)"
+                      % (n_patch, t_patch * 1e3, n_mups, t_mups * 1e3, n_net, cores, t_net * 1e3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=100000, help="points per cloud (= queries per rank per step)")
+    ap.add_argument("--batch", type=int, default=4096, help="queries per library call")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = NestiConfig()
+    W = weights.synthetic_weights(cfg)
+    est = NormalEstimator(cfg, W, dtype=args.dtype, device=dev, batch=min(args.batch, args.points))
+    clouds_np = make_clouds(world, args.points)
+    clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
+    lib = _lib.load()
+
+    def step():
+        last = None
+        for c in clouds:
+            c.build_grid()                                    # search structure: part of the path
+            last = ndist.estimate_sharded(est, c)
+        return last
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    timing = (rank == 0) and not args.no_kernel_timing
+    sync()
+    if timing:
+        lib.nesti_profile_enable(1)
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    prof_ms = (ctypes.c_double * 4)()
+    prof_n = (ctypes.c_longlong * 4)()
+    if timing:
+        lib.nesti_profile_read(prof_ms, prof_n)
+        lib.nesti_profile_enable(0)
+
+    if rank == 0:
+        total_normals = world * args.points * args.steps
+        normals, expert, probs = [t.cpu().numpy() for t in out]
+        hist = np.bincount(expert, minlength=cfg.n_experts)
+        res = {
+            "metric": "normals/sec (whole node), synthetic 100k-pt clouds", "value": total_normals / elapsed,
+            "unit": "normals/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "full MoE hot path (ball query + MuPS 3 scales 8^3 + gate + top-1 of 7 experts), "
+                                   "%d cloud(s) x %d points, rows sharded over %d rank(s) + all-gather"
+                                   % (world, args.points, world),
+                       "points_per_cloud": args.points, "batch": est.batch, "weights": "synthetic seed %d" % weights.WEIGHT_SEED,
+                       "routing_histogram": hist.tolist(), "parallelism": "dp%d (query rows)" % world},
+            "rms_angle_deg_vs_analytic": rms_angle_deg(normals, clouds_np[-1][1]),
+        }
+        if timing:
+            h = est.net._handle
+            nom, use, iss = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            macs = {}
+            for tw in range(-1, cfg.n_experts):
+                lib.nesti_model_macs(h, tw, ctypes.byref(nom), ctypes.byref(use), ctypes.byref(iss))
+                macs[tw] = (nom.value, use.value, iss.value)
+            # rank 0's queries per step: its shard of every cloud; routing of the last cloud stands in for all
+            frac = hist / max(1, hist.sum())
+            per_pt = [macs[-1][j] + sum(frac[e] * macs[e][j] for e in range(cfg.n_experts)) for j in range(3)]
+            rank0_pts = args.points * args.steps
+            conv_s = prof_ms[0] / 1e3
+            ach = [2.0 * per_pt[j] * rank0_pts / conv_s / 1e12 for j in range(3)]
+            peak = PEAK_TFLOPS[args.dtype]
+            res["roofline"] = {
+                "bound": "mfma", "kernel": "conv_igemm_kernel (all conv3d/fc layers)", "achieved": ach[1], "peak": peak,
+                "unit": "TFLOP/s", "frac": ach[1] / peak, "traffic": None,
+                "algorithmic_gflop_per_point": 2 * per_pt[1] / 1e9, "nominal_tflops": ach[0], "issued_tflops": ach[2],
+                "launches": int(prof_n[0]), "avg_launch_ms": prof_ms[0] / max(1, prof_n[0]),
+                "kernel_ms_per_step": {k: prof_ms[i] / args.steps for i, k in enumerate(_lib.PROF_CATEGORIES)},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, W, clouds_np[0][0])
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -162,6 +162,23 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
                   int B, void* ws_dev, size_t ws_bytes, float* normals_out_dev,
                   int32_t* expert_out_dev, float* probs_out_dev, void* stream);
 
+/* ---- measurement support (bench.py's roofline leg; no reference counterpart) ------------
+ * nesti_profile_enable(1) makes every kernel launch of the forward path record a pair of
+ * hipEvents on its stream; nesti_profile_read() synchronises on them and returns, per
+ * category, the summed kernel time in ms and the number of launches since enable.
+ * Not thread-safe; leave it off outside measurements. */
+enum { NESTI_PROF_CONV = 0, NESTI_PROF_MUPS = 1, NESTI_PROF_POOL = 2, NESTI_PROF_PATCHES = 3,
+       NESTI_PROF_CATEGORIES = 4 };
+int nesti_profile_enable(int on);
+int nesti_profile_read(double* ms /*[NESTI_PROF_CATEGORIES]*/,
+                       long long* launches /*[NESTI_PROF_CATEGORIES]*/);
+/* Multiply-accumulates per point of one tower (tower = -1: gating net, 0..E-1: expert):
+ *   nominal = dense conv as TensorFlow executes it (zero-padding taps included),
+ *   useful  = taps that land inside the volume only (the algorithmic figure),
+ *   issued  = what the MFMA kernels actually issue (channel padding included). */
+int nesti_model_macs(const nesti_model_t* m, int tower, double* nominal, double* useful,
+                     double* issued);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,7 +46,12 @@ SIGNATURES = {
     "nesti_gate_forward": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
     "nesti_experts_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "nesti_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "nesti_profile_enable": (_i, [_i]),
+    "nesti_profile_read": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
+    "nesti_model_macs": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                              ctypes.POINTER(ctypes.c_double)]),
 }
+PROF_CATEGORIES = ("conv", "mups", "pool", "patches")
 
 _lib = None
 

@@ -69,6 +69,10 @@ template <> struct Elem<NESTI_F16> {
 uint16_t host_f32_to_bf16(float f);
 uint16_t host_f32_to_f16(float f);
 
+// ---- optional kernel timing (model.hip) -----------------------------------------
+void prof_begin(int category, hipStream_t st);
+void prof_end(int category, hipStream_t st);
+
 // ---- launchers implemented in the .hip files -------------------------------
 int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n_eff, int B,
                 void* out, int out_dtype, int out_cstride, hipStream_t stream);

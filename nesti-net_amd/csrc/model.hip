@@ -20,6 +20,48 @@ namespace nesti {
 static thread_local std::string g_error;
 void set_error(const std::string& msg) { g_error = msg; }
 
+// ------------------------------------------------------------------------------------------
+// optional per-category kernel timing with hipEvents on the launch stream (bench.py roofline leg)
+// ------------------------------------------------------------------------------------------
+struct ProfState {
+  bool on = false;
+  std::vector<hipEvent_t> pool;      // recycled events
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[NESTI_PROF_CATEGORIES];
+  double ms[NESTI_PROF_CATEGORIES] = {0};
+  long long launches[NESTI_PROF_CATEGORIES] = {0};
+};
+static ProfState g_prof;
+
+static hipEvent_t prof_event() {
+  if (!g_prof.pool.empty()) { hipEvent_t e = g_prof.pool.back(); g_prof.pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_begin(int cat, hipStream_t st) {
+  if (!g_prof.on) return;
+  hipEvent_t a = prof_event(), b = prof_event();
+  (void)hipEventRecord(a, st);
+  g_prof.spans[cat].push_back({a, b});
+}
+void prof_end(int cat, hipStream_t st) {
+  if (!g_prof.on) return;
+  (void)hipEventRecord(g_prof.spans[cat].back().second, st);
+}
+static void prof_collect() {
+  for (int c = 0; c < NESTI_PROF_CATEGORIES; ++c) {
+    for (auto& sp : g_prof.spans[c]) {
+      (void)hipEventSynchronize(sp.second);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, sp.first, sp.second) == hipSuccess) g_prof.ms[c] += ms;
+      g_prof.launches[c] += 1;
+      g_prof.pool.push_back(sp.first);
+      g_prof.pool.push_back(sp.second);
+    }
+    g_prof.spans[c].clear();
+  }
+}
+
 uint16_t host_f32_to_bf16(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -407,7 +449,10 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, const void* P0, 
       const long long rows = (long long)rc.NB << (3 * d.log2S);
       p.m_tiles = (int)((rows + kTileM - 1) / kTileM);
       memcpy(p.tap, pl.tap, sizeof(p.tap));
-      if (launch_conv(p, dtype, pl.TN, pl.n_tiles, rc.stream)) return 1;
+      prof_begin(NESTI_PROF_CONV, rc.stream);
+      const int rcv = launch_conv(p, dtype, pl.TN, pl.n_tiles, rc.stream);
+      prof_end(NESTI_PROF_CONV, rc.stream);
+      if (rcv) return 1;
     } else {
       PoolParams p;
       memset(&p, 0, sizeof(p));
@@ -417,8 +462,10 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, const void* P0, 
       p.in_cstride = T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
       p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
       p.C = op.C; p.log2S = op.log2S; p.k = op.k;
-      if (op.kind == Op::AVG) { if (launch_avgpool(p, dtype, rc.stream)) return 1; }
-      else { if (launch_maxpool2(p, dtype, rc.stream)) return 1; }
+      prof_begin(NESTI_PROF_POOL, rc.stream);
+      const int rcp = (op.kind == Op::AVG) ? launch_avgpool(p, dtype, rc.stream) : launch_maxpool2(p, dtype, rc.stream);
+      prof_end(NESTI_PROF_POOL, rc.stream);
+      if (rcp) return 1;
     }
   }
   *out = reinterpret_cast<float*>(ptr[T.out_buf]);
@@ -432,7 +479,10 @@ int pool_mups(const nesti_model* m, const void* X0, void* P0, int B, hipStream_t
   p.in = X0; p.out = P0; p.npoints = B;
   p.in_cstride = p.out_cstride = p.C = m->graph.mups_cstride;
   p.log2S = 3; p.k = 3;
-  return launch_avgpool(p, m->dtype, stream);
+  prof_begin(NESTI_PROF_POOL, stream);
+  const int rc = launch_avgpool(p, m->dtype, stream);
+  prof_end(NESTI_PROF_POOL, stream);
+  return rc;
 }
 
 size_t max_tower_bytes(const nesti_model* m, int NB) {
@@ -537,7 +587,10 @@ int nesti_gmm_grid(int n, double variance, float* w, float* mu, float* sigma) {
 int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev, const int32_t* n_eff_dev, int B,
                        void* out_dev, int out_dtype, int out_cstride, void* stream) {
   if (!cfg || !points_dev || !n_eff_dev || !out_dev) NESTI_FAIL("nesti_mups_forward: null argument");
-  return launch_mups(cfg, points_dev, n_eff_dev, B, out_dev, out_dtype, out_cstride, (hipStream_t)stream);
+  prof_begin(NESTI_PROF_MUPS, (hipStream_t)stream);
+  const int rc = launch_mups(cfg, points_dev, n_eff_dev, B, out_dev, out_dtype, out_cstride, (hipStream_t)stream);
+  prof_end(NESTI_PROF_MUPS, (hipStream_t)stream);
+  return rc;
 }
 
 int nesti_model_describe(const nesti_config_t* cfg, int* n_tensors, nesti_tensor_t* infos, int max_infos) {
@@ -630,7 +683,10 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   hipStream_t st = (hipStream_t)stream;
   void* X0 = ws + L.x0;
   void* P0 = ws + L.p0;
-  if (launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride, st)) return 1;
+  prof_begin(NESTI_PROF_MUPS, st);
+  const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride, st);
+  prof_end(NESTI_PROF_MUPS, st);
+  if (rcm) return 1;
   if (pool_mups(m, X0, P0, B, st)) return 1;
   float* probs = probs_out_dev ? probs_out_dev : (float*)(ws + L.probs);
   int32_t* expert = expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert);
@@ -638,6 +694,49 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   int32_t* lists = (int32_t*)(ws + L.lists);
   if (gate_impl(m, X0, P0, B, ws + L.tower, L.total - L.tower, probs, expert, counts, lists, st)) return 1;
   return experts_impl(m, X0, P0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
+}
+
+int nesti_profile_enable(int on) {
+  prof_collect();
+  for (int c = 0; c < NESTI_PROF_CATEGORIES; ++c) { g_prof.ms[c] = 0; g_prof.launches[c] = 0; }
+  g_prof.on = on != 0;
+  return 0;
+}
+
+int nesti_profile_read(double* ms, long long* launches) {
+  prof_collect();   // synchronises on the recorded events
+  for (int c = 0; c < NESTI_PROF_CATEGORIES; ++c) {
+    if (ms) ms[c] = g_prof.ms[c];
+    if (launches) launches[c] = g_prof.launches[c];
+  }
+  return 0;
+}
+
+int nesti_model_macs(const nesti_model_t* m, int tower, double* nominal, double* useful, double* issued) {
+  if (!m) NESTI_FAIL("nesti_model_macs: null model");
+  const int E = m->graph.cfg.n_experts;
+  if (tower < -1 || tower >= E) NESTI_FAIL("nesti_model_macs: tower must be -1 (gate) or an expert index");
+  const Tower& T = tower < 0 ? m->graph.gate : m->graph.experts[tower];
+  double nom = 0, use = 0, iss = 0;
+  for (const Op& op : T.ops) {
+    if (op.kind != Op::CONV) continue;
+    const LayerDesc& d = m->graph.layers[op.layer];
+    const PackedLayer& pl = m->packed[op.layer];
+    const int S = 1 << d.log2S, V = S * S * S, lo = (d.k - 1) / 2;
+    long long valid = 0;   // sum over output voxels of the taps that land inside the volume
+    for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)
+      for (int a = 0; a < d.k; ++a) for (int b = 0; b < d.k; ++b) for (int c = 0; c < d.k; ++c) {
+        const int zz = z + a - lo, yy = y + b - lo, xx = x + c - lo;
+        if (zz >= 0 && zz < S && yy >= 0 && yy < S && xx >= 0 && xx < S) ++valid;
+      }
+    nom += (double)V * d.k * d.k * d.k * d.cin * d.cout;
+    use += (double)valid * d.cin * d.cout;
+    iss += (double)V * pl.n_taps * d.Cin_p * d.Cout_p;
+  }
+  if (nominal) *nominal = nom;
+  if (useful) *useful = use;
+  if (issued) *issued = iss;
+  return 0;
 }
 
 }  // extern "C"

@@ -373,7 +373,9 @@ int nesti_patches_query(const nesti_config_t* cfg, const float* cloud_dev, int N
     p.rad_f[s] = (float)r_abs[s];
   }
   p.points_out = points_out_dev; p.n_eff_out = n_eff_out_dev; p.nbr_out = nbr_idx_out_dev; p.n_ball_out = n_ball_out_dev;
+  prof_begin(NESTI_PROF_PATCHES, (hipStream_t)stream);
   hipLaunchKernelGGL(patches_kernel, dim3(M), dim3(kThreads), 0, (hipStream_t)stream, p);
+  prof_end(NESTI_PROF_PATCHES, (hipStream_t)stream);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

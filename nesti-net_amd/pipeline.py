@@ -1,0 +1,53 @@
+"""End-to-end hot path for one shape: cloud (host or device) -> multi-scale patches (HIP ball
+query) -> MuPS -> gating -> top-1 expert -> normals.  This is the body of the reference's
+``predict`` loop (``test_n_est_w_experts.py:129-152``) with the per-point Python
+``__getitem__`` and the TF ``sess.run`` replaced by three library calls per batch."""
+import numpy as np
+import torch
+
+from .config import NestiConfig
+from .model import NestiNet
+from .provider import CloudPatches
+
+
+class NormalEstimator:
+    def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", batch=4096, seed=3627473):
+        self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
+        self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=self.batch)
+        S, P = cfg.n_scales, cfg.num_point
+        self._points = torch.empty((self.batch, S * P, 3), dtype=torch.float32, device=self.device)
+        self._n_eff = torch.empty((self.batch, S), dtype=torch.int32, device=self.device)
+
+    def prepare(self, pts, pidx=None):
+        """Upload a cloud and build its search grid (replaces ``load_shape``)."""
+        return CloudPatches(pts, self.cfg, device=self.device, seed=self.seed, pidx=pidx)
+
+    def run(self, cloud: CloudPatches, first=0, count=None, out=None):
+        """Normals for patch rows [first, first+count) of a prepared cloud.
+
+        Returns (normals [count,3] f32, expert [count] int32, probs [count,E] f32) on the device;
+        everything is enqueued on the current stream, nothing synchronises."""
+        count = cloud.patch_count - first if count is None else count
+        E = self.cfg.n_experts
+        if out is None:
+            normals = torch.empty((count, 3), dtype=torch.float32, device=self.device)
+            expert = torch.empty((count,), dtype=torch.int32, device=self.device)
+            probs = torch.empty((count, E), dtype=torch.float32, device=self.device)
+        else:
+            normals, expert, probs = out
+        done = 0
+        while done < count:
+            take = min(self.batch, count - done)
+            p, n = self._points[:take], self._n_eff[:take]
+            cloud.build(first + done, take, out=(p, n))
+            sl = slice(done, done + take)
+            self.net.forward(p, n, out=(normals[sl], expert[sl], probs[sl]))
+            done += take
+        return normals, expert, probs
+
+    def estimate(self, pts, pidx=None):
+        """Convenience: numpy cloud in, numpy results out (synchronises)."""
+        cloud = self.prepare(np.asarray(pts, dtype=np.float32), pidx)
+        normals, expert, probs = self.run(cloud)
+        torch.cuda.synchronize(self.device)
+        return normals.cpu().numpy(), expert.cpu().numpy(), probs.cpu().numpy()

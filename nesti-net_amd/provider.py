@@ -56,9 +56,14 @@ class CloudPatches:
         self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self._c = cfg.to_c()
         self._r = (ctypes.c_double * len(self.r_abs))(*self.r_abs)
+        self.build_grid()
+
+    def build_grid(self, stream=None):
+        """(Re)build the uniform search grid on the device -- the cKDTree construction of the
+        reference (``utils/pcpnet_dataset.py:37``).  Asynchronous on ``stream``."""
         with torch.cuda.device(self.device):
             _lib.check(self.lib.nesti_patches_grid(ctypes.byref(self._c), _lib.ptr(self.cloud), self.n_points, self._r,
-                                                   _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()),
+                                                   _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr(stream)),
                        "nesti_patches_grid")
 
     def build(self, first, count, want_idx=False, out=None, stream=None):

@@ -102,6 +102,21 @@ def test_f32_forward_top1_matches_oracle_and_all_experts(setup, oracle_out, net_
     assert torch.equal(routed, normals)
 
 
+def test_explicit_routing_to_every_expert(setup, net_f32, gpu_device):
+    """Top-1 execution with a caller-supplied assignment that uses every expert (one of them for
+    zero points, one for a single point) equals select-after-evaluate-all."""
+    cfg, W, pts, n_eff = setup
+    p = torch.as_tensor(pts, device=gpu_device)
+    n = torch.as_tensor(n_eff, device=gpu_device)
+    mups = net_f32.mups(p, n)
+    n_est = net_f32.experts(mups, None)
+    B = p.shape[0]
+    assign = torch.tensor([0, 6, 2, 3, 4, 6, 6, 0, 2, 2, 3, 4, 0, 1, 6, 3][:B], dtype=torch.int32, device=gpu_device)   # no 5
+    routed = net_f32.experts(mups, assign)
+    sel = n_est[assign.long(), torch.arange(B, device=gpu_device)]
+    assert torch.equal(routed, sel)
+
+
 @pytest.mark.parametrize("dtype,cos_tol,prob_tol", [("bf16", 2e-3, 5e-2), ("f16", 5e-5, 1e-2)])
 def test_16bit_modes_close_to_oracle(setup, oracle_out, gpu_device, dtype, cos_tol, prob_tol):
     from nesti_net_amd.model import NestiNet
