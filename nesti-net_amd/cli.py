@@ -1,0 +1,86 @@
+"""Command-line drop-in for the reference's ``test_n_est_w_experts.py``: same flags
+(``:19-29``), same inputs (``<dataset_path>/<testset>`` shape list, ``<shape>.xyz``, optional
+``<shape>.pidx``) and same outputs (``<results_path>/<dataset_name>_results/<shape>.normals``,
+``.experts``, ``.experts_probs`` written with ``np.savetxt`` like ``:182-188``, plus ``log.txt``).
+
+The trained-model directory holds ``model.nstw`` (variables + hyper-parameters, see
+:mod:`.weights`) instead of ``parameters.p`` / ``gmm.p`` / ``model.ckpt``; ``--synthetic_weights``
+substitutes seeded random weights (no checkpoint ships with the reference)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import weights as wts
+from .config import NestiConfig
+from .pipeline import NormalEstimator
+from .provider import PointcloudPatchDataset
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--results_path", default="log/my_experts/", help="path to trained model, default log/my_experts/")
+    p.add_argument("--model", default="experts_n_est", help="Model name [default: experts_n_est]")
+    p.add_argument("--dataset_name", type=str, default="pcpnet", help="Relative path to data directory, default pcpnet")
+    p.add_argument("--dataset_path", type=str, default=None, help="full path to dataset for datasets outside the local data dir")
+    p.add_argument("--sparse_patches", type=int, default=False,
+                   help="test on a subset of the points in each point cloud in the test data, default False")
+    p.add_argument("--gpu", type=int, default=0, help="GPU to use [default: GPU 0]")
+    p.add_argument("--batch_size", type=int, default=128, help="Batch size [default: 128]; the library batches internally")
+    p.add_argument("--testset", type=str, default="testset_temp.txt", help="test set file name, default testset_temp.txt")
+    # extensions (not in the reference)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"], help="MFMA precision mode")
+    p.add_argument("--synthetic_weights", action="store_true", help="use seeded synthetic weights if model.nstw is absent")
+    return p
+
+
+def main(argv=None):
+    FLAGS = build_parser().parse_args(argv)
+    if FLAGS.model != "experts_n_est":
+        raise SystemExit("only --model experts_n_est (the mixture-of-experts hot path) is implemented")
+    results_path = FLAGS.results_path
+    base = os.getcwd()
+    pc_path = FLAGS.dataset_path if FLAGS.dataset_path is not None else os.path.join(base, "data/" + FLAGS.dataset_name + "/")
+    output_dir = os.path.join(results_path, FLAGS.dataset_name + "_results/")
+    os.makedirs(output_dir, exist_ok=True)
+    flog = open(os.path.join(output_dir, "log.txt"), "w")
+
+    def printout(data):
+        print(data)
+        flog.write(data + "\n")
+        sys.stdout.flush()
+
+    model_file = os.path.join(results_path, "model.nstw")
+    if os.path.exists(model_file):
+        printout("Loading model %s" % model_file)
+        W, cfg = wts.load(model_file)
+        cfg = cfg or NestiConfig()
+    elif FLAGS.synthetic_weights:
+        cfg = NestiConfig()
+        printout("No %s: using synthetic weights (seed %d)" % (model_file, wts.WEIGHT_SEED))
+        W = wts.synthetic_weights(cfg)
+    else:
+        raise SystemExit("%s not found (pass --synthetic_weights to run without a trained model)" % model_file)
+    device = "cuda:%d" % FLAGS.gpu
+    est = NormalEstimator(cfg, W, dtype=FLAGS.dtype, device=device, batch=max(FLAGS.batch_size, 4096))
+    printout("Model restored.")
+
+    dataset = PointcloudPatchDataset(pc_path, FLAGS.testset, cfg, seed=3627473, sparse_patches=FLAGS.sparse_patches,
+                                     device=device)
+    for ind, name in enumerate(dataset.shape_names):
+        cloud = dataset.get_shape(ind)
+        normals, expert, probs = est.run(cloud)
+        torch.cuda.synchronize()
+        np.savetxt(os.path.join(output_dir, name + ".normals"), normals.cpu().numpy().astype(np.float64))
+        printout("saved normals for " + name)
+        np.savetxt(os.path.join(output_dir, name + ".experts"), expert.cpu().numpy().astype(int), fmt="%i")
+        np.savetxt(os.path.join(output_dir, name + ".experts_probs"), probs.cpu().numpy().astype(np.float64))
+        printout("saved experts for " + name)
+    flog.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,27 +1,38 @@
 // Implicit-GEMM conv3d / fully-connected kernel on the gfx950 matrix cores.
 //
 // Replaces tf.nn.conv3d + bias_add + inference batch-norm + ReLU
-// (utils/tf_util.py:298-311, 491-494) and tf.matmul + bias (+BN, ReLU)
-// (utils/tf_util.py:340-351).  BN is folded into weights/bias on the host
-// (model.hip), so the epilogue is bias + optional ReLU.
+// (utils/tf_util.py:298-311, 491-494), tf.matmul + bias (+BN, ReLU)
+// (utils/tf_util.py:340-351) and -- fused into the epilogue -- the k^3 stride-1 SAME
+// tf.nn.avg_pool3d of the inception pool branch (utils/tf_util.py:450-454,
+// models/experts_n_est.py:307-310).  BN is folded into weights/bias on the host (model.hip).
 //
 // Decomposition (one 512-thread workgroup = 8 wave64):
 //   M tile  = 512 GEMM rows = whole points (1 point at 8^3, 8 at 4^3, 64 at 2^3, 512 for FC),
 //             so every tap of every output voxel finds its input row inside the tile:
-//             the K-chunk of the input is staged into LDS ONCE and re-read for all k^3 taps
+//             a K-chunk of the input is staged into LDS ONCE and re-read for all k^3 taps
 //             (the halo never goes back to HBM/L2);
 //   N tile  = TN (64 or 128) output channels;
 //   K loop  = input-channel chunks (128 bytes per row: 64 x bf16/f16 or 32 x f32) outer,
-//             taps inner; per (chunk, tap) a TN x 128 B weight tile is streamed from L2
-//             into a double-buffered LDS slot while the previous tap's MFMAs run.
+//             taps inner; per (chunk, tap) a TN x 128 B weight tile streams from L2 straight
+//             into a double-buffered LDS slot (global_load_lds, no VGPR round trip) while the
+//             current tap's MFMAs run;
 //   wave w  = rows [64w, 64w+64) x all TN columns: 2 x (TN/32) tiles of 32x32, fp32 accumulate.
-// LDS rows are 128 B with the 16-B slot index XOR-swizzled by (row>>1)&7, which makes the
-// ds_read_b128 fragment loads of 32 consecutive rows conflict-free (guide: T2).
-// Zero padding is a per-lane predicate on the A-fragment load, never a memory halo.
+// LDS rows are 128 B with the 16-B slot index XOR-swizzled by (row>>1)&7 (applied on the global
+// SOURCE address, since global_load_lds writes lane-linear), which makes the ds_read_b128
+// fragment loads of 32 consecutive rows conflict-free.  Zero padding is an address select: a
+// lane whose tap leaves the volume reads a dedicated all-zero LDS row.
+//
+// 1x1x1 / FC layers (one tap) use the KPIPE variant: A and B chunks are double-buffered and
+// chunk c+1 streams in while chunk c multiplies.  An inception's conv1 and conv4 share their
+// input, so they run as ONE launch (column tiles >= split_tile belong to conv4); because
+// avg-pool and a 1x1 conv commute, conv4's tiles average the fp32 accumulators over the k^3
+// window (divisor = taps inside the volume) in the epilogue instead of pooling the input first.
 //
 // 16-bit mode uses v_mfma_f32_32x32x16_{bf16,f16}; the f32 parity mode uses
 // v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain) on the same LDS image: a lane's 16 bytes are
 // 8 consecutive k (16-bit) or 4 consecutive k (f32) and A and B use the same k order.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace nesti {
@@ -47,20 +58,45 @@ template <> __device__ __forceinline__ void mma<NESTI_F32>(f32x16& acc, const ui
 
 constexpr int kThreads = 512;
 constexpr int kABytes = kTileM * kRowBytes;   // 64 KiB
+constexpr int kPoolStride = 272;              // bytes per row of the fp32 [512][64] pooling tile (+16 B pad)
 
-template <int DT, int TN>
+typedef __attribute__((address_space(3))) unsigned char* lptr_t;
+
+// 16 B per lane, global -> LDS, asynchronous LDS-DMA.  Issued through inline asm so that hipcc does not
+// track it: with the builtin the compiler parks an s_waitcnt vmcnt(0) in front of the next ds_read and the
+// weight-tile latency is exposed on every tap.  Completion is waited for by hand (wait_vm0) before the
+// barrier that publishes the tile.  lds_dst is a wave-uniform LDS byte address; lane i lands at lds_dst + 16 i.
+__device__ __forceinline__ void glds16(const unsigned char* src, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(src), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int DT, int TN, bool KPIPE>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* As = smem;
-  unsigned char* Bs = smem + kABytes;
   constexpr int NI = TN / 32;
   constexpr int kBTile = TN * kRowBytes;
-  constexpr int kBVec = kBTile / 16 / kThreads;   // uint4 per thread per weight tile
+  constexpr int kBVec = TN / 64;                  // 1-KiB pieces of a weight tile per wave
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
+  constexpr int kNA = KPIPE ? 2 : 1;              // A buffers
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + kNA * kABytes;
+  constexpr int kZeroOff = kNA * kABytes + 2 * kBTile;   // all-zero 128-B row (general variant only)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m_tile = blockIdx.x % p.m_tiles;
-  const int n_tile = blockIdx.x / p.m_tiles;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware block -> tile map: the 8 blocks of a dispatch group land on the 8 XCDs; each XCD
+  // keeps its M tile and walks the N tiles, so the staged input stays in that XCD's L2.
+  const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
+  const int n_tile = grp % p.n_tiles;
+  const int m_tile = (grp / p.n_tiles) * 8 + xcd;
+  if (m_tile >= p.m_tiles) return;
   int npts = p.npoints;
   if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
   const int log2S = p.log2S, log2V = 3 * log2S;
@@ -69,23 +105,41 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   const long long r0 = (long long)m_tile * kTileM;
   if (r0 >= total_rows) return;
 
-  // ---- A staging: thread -> (slot, rows (tid>>3) + 64 j) --------------------------------
-  const int a_slot = tid & 7;
-  const int a_row0 = tid >> 3;
+  // ---- A staging: wave w, piece j covers LDS rows (w*8+j)*8 .. +8; lane -> (row, slot') ----------
   long long a_off[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const long long gr = r0 + a_row0 + 64 * j;
+    const int row_l = (wave * 8 + j) * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ ((row_l >> 1) & 7);       // inverse swizzle on the SOURCE
+    const long long gr = r0 + row_l;
     if (gr < total_rows) {
       long long pt = gr >> log2V;
       const long long vox = gr & (V - 1);
       if (p.point_index) pt = p.point_index[pt];
-      a_off[j] = (((pt << log2V) + vox) * p.in_cstride + p.in_coff) * kEsz + a_slot * 16;
+      a_off[j] = (((pt << log2V) + vox) * p.in_cstride + p.in_coff) * kEsz + slot * 16;
     } else {
       a_off[j] = -1;
     }
   }
-  const int a_dst = a_row0 * kRowBytes + ((a_slot ^ ((a_row0 >> 1) & 7)) << 4);   // + j*64*128
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+  const unsigned char* w_tile =
+      reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)n_tile * p.n_chunks * p.n_taps * kBTile;
+
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic segment
+  auto stage_a = [&](int c, int a_buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (a_off[j] >= 0)
+        glds16(in_b + a_off[j] + (long long)c * kRowBytes, lds0 + a_buf * kABytes + (wave * 8 + j) * 1024);
+  };
+  auto stage_b = [&](int c, int t, int b_buf) {
+    const unsigned char* src = w_tile + ((size_t)c * p.n_taps + t) * kBTile;
+#pragma unroll
+    for (int q = 0; q < kBVec; ++q) {
+      const int piece = wave * kBVec + q;
+      glds16(src + piece * 1024 + lane * 16, lds0 + kNA * kABytes + b_buf * kBTile + piece * 1024);
+    }
+  };
 
   // ---- per-lane fragment coordinates ----------------------------------------------------
   int rz[2], ry[2], rx[2], rrow[2];
@@ -109,87 +163,159 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
-  const unsigned char* w_tile =
-      reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)n_tile * p.n_chunks * p.n_taps * kBTile;
+  // one (chunk, tap) step: 4 K-steps of 2 x NI MFMAs
+  auto compute = [&](const unsigned char* Acur, const unsigned char* Bcur, const int (&a_addr)[2], const int (&a_sw)[2]) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int slot = kk * 2 + khalf;
+      uint4 a[2], b[NI];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+        a[mi] = *reinterpret_cast<const uint4*>(Acur + a_addr[mi] + ((slot ^ a_sw[mi]) << 4));
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        b[ni] = *reinterpret_cast<const uint4*>(Bcur + ni * 32 * kRowBytes + b_row + ((slot ^ b_sw) << 4));
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[mi][ni], a[mi], b[ni]);
+    }
+  };
 
-  for (int c = 0; c < p.n_chunks; ++c) {
-    // stage A(c) and B(c, tap 0)
-    uint4 av[8];
+  if constexpr (KPIPE) {
+    // ---- one tap: software pipeline over input-channel chunks --------------------------------
+    int a_addr[2], a_sw[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      av[j] = make_uint4(0, 0, 0, 0);
-      if (a_off[j] >= 0) av[j] = *reinterpret_cast<const uint4*>(in_b + a_off[j] + (long long)c * kRowBytes);
-    }
-    uint4 bpre[kBVec];
-    {
-      const unsigned char* src = w_tile + (size_t)c * p.n_taps * kBTile;
-#pragma unroll
-      for (int q = 0; q < kBVec; ++q) bpre[q] = *reinterpret_cast<const uint4*>(src + (tid + q * kThreads) * 16);
-    }
-    __syncthreads();   // every wave is done with the previous chunk's A and B tiles
-#pragma unroll
-    for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(As + a_dst + j * 64 * kRowBytes) = av[j];
-#pragma unroll
-    for (int q = 0; q < kBVec; ++q) *reinterpret_cast<uint4*>(Bs + (tid + q * kThreads) * 16) = bpre[q];
+    for (int mi = 0; mi < 2; ++mi) { a_addr[mi] = rrow[mi] * kRowBytes; a_sw[mi] = (rrow[mi] >> 1) & 7; }
+    stage_a(0, 0);
+    stage_b(0, 0, 0);
+    wait_vm0();
     __syncthreads();
-
-    for (int t = 0; t < p.n_taps; ++t) {
-      const bool more = (t + 1 < p.n_taps);
-      if (more) {
-        const unsigned char* src = w_tile + ((size_t)c * p.n_taps + t + 1) * kBTile;
-#pragma unroll
-        for (int q = 0; q < kBVec; ++q) bpre[q] = *reinterpret_cast<const uint4*>(src + (tid + q * kThreads) * 16);
+    for (int c = 0; c < p.n_chunks; ++c) {
+      const int cur = c & 1;
+      if (c + 1 < p.n_chunks) {
+        stage_a(c + 1, cur ^ 1);
+        stage_b(c + 1, 0, cur ^ 1);
       }
-      const unsigned char* Bcur = Bs + (t & 1) * kBTile;
-      const int dz = p.tap[t][0], dy = p.tap[t][1], dx = p.tap[t][2];
-      const int shift = dz * (1 << (2 * log2S)) + dy * S + dx;
-      bool ok[2];
-      int a_base[2], a_sw[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
-        ok[mi] = ((unsigned)(rz[mi] + dz) < (unsigned)S) & ((unsigned)(ry[mi] + dy) < (unsigned)S) &
-                 ((unsigned)(rx[mi] + dx) < (unsigned)S);
-        const int srow = rrow[mi] + shift;
-        a_base[mi] = srow * kRowBytes;
-        a_sw[mi] = (srow >> 1) & 7;
-      }
-      if (__ballot(ok[0] | ok[1]) != 0ull) {   // whole-wave zero taps (z-plane halo): skip the MFMAs
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int slot = kk * 2 + khalf;
-          uint4 a[2], b[NI];
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
-            a[mi] = make_uint4(0, 0, 0, 0);
-            if (ok[mi]) a[mi] = *reinterpret_cast<const uint4*>(As + a_base[mi] + ((slot ^ a_sw[mi]) << 4));
-          }
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            b[ni] = *reinterpret_cast<const uint4*>(Bcur + ni * 32 * kRowBytes + b_row + ((slot ^ b_sw) << 4));
-#pragma unroll
-          for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[mi][ni], a[mi], b[ni]);
-        }
-      }
-      if (more) {
-        unsigned char* Bnext = Bs + ((t + 1) & 1) * kBTile;
-#pragma unroll
-        for (int q = 0; q < kBVec; ++q) *reinterpret_cast<uint4*>(Bnext + (tid + q * kThreads) * 16) = bpre[q];
-      }
+      compute(As + cur * kABytes, Bs + cur * kBTile, a_addr, a_sw);
+      wait_vm0();
       __syncthreads();
+    }
+  } else {
+    // ---- k^3 taps: A chunk resident, weight tiles double-buffered -----------------------------
+    if (tid < 32) reinterpret_cast<uint32_t*>(smem + kZeroOff)[tid] = 0u;
+    for (int c = 0; c < p.n_chunks; ++c) {
+      __syncthreads();   // every wave is done with the previous chunk's tiles
+      stage_a(c, 0);
+      stage_b(c, 0, 0);
+      wait_vm0();
+      __syncthreads();
+      for (int t = 0; t < p.n_taps; ++t) {
+        if (t + 1 < p.n_taps) stage_b(c, t + 1, (t + 1) & 1);
+        const int dz = p.tap[t][0], dy = p.tap[t][1], dx = p.tap[t][2];
+        const int shift = dz * (1 << (2 * log2S)) + dy * S + dx;
+        int a_addr[2], a_sw[2];
+        bool any_ok = false;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const bool ok = ((unsigned)(rz[mi] + dz) < (unsigned)S) & ((unsigned)(ry[mi] + dy) < (unsigned)S) &
+                          ((unsigned)(rx[mi] + dx) < (unsigned)S);
+          const int srow = rrow[mi] + shift;
+          a_addr[mi] = ok ? srow * kRowBytes : kZeroOff;   // padding tap -> the zero row
+          a_sw[mi] = ok ? ((srow >> 1) & 7) : 0;
+          any_ok |= ok;
+        }
+        if (__ballot(any_ok) != 0ull)   // a whole-wave padding tap (z-plane halo) issues no MFMAs
+          compute(As, Bs + (t & 1) * kBTile, a_addr, a_sw);
+        wait_vm0();
+        __syncthreads();
+      }
     }
   }
 
-  // ---- epilogue: bias + ReLU, transpose through a wave-private LDS scratch, 16-B stores ---
-  // (the barrier that ended the last tap guarantees nobody still reads As)
-  unsigned char* scratch = smem + wave * 8192;
+  // ---- epilogue (the barrier that ended the last step guarantees nobody still reads A/B) -------
   const int out_esz = p.out_f32 ? 4 : kEsz;
+  unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
+  const bool second = n_tile >= p.split_tile;            // conv4 half of a merged conv1|conv4 launch
+  const int n_local = second ? n_tile - p.split_tile : n_tile;
+  const int out_col0 = (second ? p.out_coff2 : p.out_coff) + n_local * TN;
+  const float* bias = p.bias + n_tile * TN;
+
+  if (KPIPE && second && p.pool_k > 1) {
+    // avg_pool3d(k, SAME, stride 1) of the pre-activation, per 64-column half, through an fp32 LDS tile
+    const int lo = (p.pool_k - 1) / 2;
+    // one call per 64-column half with a compile-time index: runtime-indexed register arrays go to scratch
+    auto pool_half = [&](auto NH) {
+      constexpr int nh = decltype(NH)::value;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int ni = nh * 2 + n2;
+          const int col = n2 * 32 + (lane & 31);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = acc[mi][ni][r];
+          }
+        }
+      __syncthreads();
+#pragma unroll 1
+      for (int it = 0; it < 16; ++it) {
+        const int item = it * kThreads + tid;
+        const int row = item >> 4, cg = item & 15;
+        const int vox = row & (V - 1);
+        const int z = vox >> (2 * log2S), y = (vox >> log2S) & (S - 1), x = vox & (S - 1);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int cnt = 0;
+        for (int a = 0; a < p.pool_k; ++a) {
+          const int zz = z + a - lo;
+          if ((unsigned)zz >= (unsigned)S) continue;
+          for (int b = 0; b < p.pool_k; ++b) {
+            const int yy = y + b - lo;
+            if ((unsigned)yy >= (unsigned)S) continue;
+            for (int c = 0; c < p.pool_k; ++c) {
+              const int xx = x + c - lo;
+              if ((unsigned)xx >= (unsigned)S) continue;
+              const int nrow = row + ((zz - z) << (2 * log2S)) + ((yy - y) << log2S) + (xx - x);
+              const float4 v = *reinterpret_cast<const float4*>(smem + nrow * kPoolStride + cg * 16);
+              s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+              ++cnt;
+            }
+          }
+        }
+        const float inv = 1.0f / (float)cnt;
+        const float4 bb = *reinterpret_cast<const float4*>(bias + nh * 64 + cg * 4);
+        float o[4] = {s.x * inv + bb.x, s.y * inv + bb.y, s.z * inv + bb.z, s.w * inv + bb.w};
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        const long long gr = r0 + row;
+        if (gr < total_rows) {
+          unsigned char* dst = out_b + (gr * p.out_cstride + out_col0 + nh * 64 + cg * 4) * out_esz;
+          if (out_esz == 4) {
+            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+            using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
+            const uint32_t w0 = (uint32_t)E::from_f32(o[0]) | ((uint32_t)E::from_f32(o[1]) << 16);
+            const uint32_t w1 = (uint32_t)E::from_f32(o[2]) | ((uint32_t)E::from_f32(o[3]) << 16);
+            *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
+          }
+        }
+      }
+      __syncthreads();
+    };
+    pool_half(std::integral_constant<int, 0>{});
+    if constexpr (TN == 128) pool_half(std::integral_constant<int, 1>{});
+    return;
+  }
+
+  // plain epilogue: bias + ReLU, transpose through a wave-private LDS scratch, 16-B stores
+  unsigned char* scratch = smem + wave * 8192;
   const int seg = 64 * out_esz;                 // bytes of one 64-channel row segment
   const int lanes_per_row = seg >> 4;           // 8 or 16
   const int rows_per_iter = 64 / lanes_per_row; // 8 or 4
-  unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -198,11 +324,11 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
       for (int n2 = 0; n2 < 2; ++n2) {
         const int ni = nh * 2 + n2;
         const int col = n2 * 32 + (lane & 31);
-        const float bias = p.bias[n_tile * TN + ni * 32 + (lane & 31)];
+        const float bv = bias[ni * 32 + (lane & 31)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-          float v = acc[mi][ni][r] + bias;
+          float v = acc[mi][ni][r] + bv;
           if (p.relu) v = fmaxf(v, 0.f);
           if (out_esz == 4) reinterpret_cast<float*>(scratch)[row * 64 + col] = v;
           else reinterpret_cast<uint16_t*>(scratch)[row * 64 + col] = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>::from_f32(v);
@@ -213,43 +339,54 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
         const int cpos = lane % lanes_per_row;
         const uint4 v = *reinterpret_cast<const uint4*>(scratch + row * seg + cpos * 16);
         const long long gr = r0 + wave * 64 + mi * 32 + row;
-        if (gr < total_rows) {
-          *reinterpret_cast<uint4*>(out_b + (gr * p.out_cstride + p.out_coff + n_tile * TN + nh * 64) * out_esz + cpos * 16) = v;
-        }
+        if (gr < total_rows)
+          *reinterpret_cast<uint4*>(out_b + (gr * p.out_cstride + out_col0 + nh * 64) * out_esz + cpos * 16) = v;
       }
     }
   }
 }
 
-template <int DT, int TN>
-int launch_one(const ConvParams& p, int n_tiles, hipStream_t stream) {
+template <int TN, bool KPIPE>
+constexpr size_t lds_bytes() {
+  return KPIPE ? (size_t)2 * kABytes + 2 * TN * kRowBytes                 // 160 KiB at TN = 128
+               : (size_t)kABytes + 2 * TN * kRowBytes + kRowBytes;       // + zero row
+}
+
+template <int DT, int TN, bool KPIPE>
+int launch_one(const ConvParams& p, hipStream_t stream) {
   static bool attr_set = false;
-  const size_t lds = kABytes + 2 * TN * kRowBytes;
+  constexpr size_t lds = lds_bytes<TN, KPIPE>();
+  static_assert(lds <= 163840, "LDS budget");
+  static_assert(!KPIPE || lds >= (size_t)kTileM * kPoolStride, "pooling tile must fit");
   if (!attr_set) {
-    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN>),
+    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN, KPIPE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  dim3 grid((unsigned)(p.m_tiles * n_tiles)), block(kThreads);
-  hipLaunchKernelGGL((conv_igemm_kernel<DT, TN>), grid, block, lds, stream, p);
+  const int groups = (p.m_tiles + 7) / 8;
+  dim3 grid((unsigned)(groups * 8 * p.n_tiles)), block(kThreads);
+  hipLaunchKernelGGL((conv_igemm_kernel<DT, TN, KPIPE>), grid, block, lds, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
+template <int DT>
+int launch_dt(const ConvParams& p, int TN, hipStream_t stream) {
+  const bool kpipe = (p.n_taps == 1);
+  if (TN == 128) return kpipe ? launch_one<DT, 128, true>(p, stream) : launch_one<DT, 128, false>(p, stream);
+  if (TN == 64) return kpipe ? launch_one<DT, 64, true>(p, stream) : launch_one<DT, 64, false>(p, stream);
+  NESTI_FAIL("launch_conv: unsupported N tile");
+}
+
 }  // namespace
 
-int launch_conv(const ConvParams& p, int dtype, int TN, int n_tiles, hipStream_t stream) {
-  if (p.m_tiles <= 0 || n_tiles <= 0) return 0;
-  if (TN == 128) {
-    if (dtype == NESTI_BF16) return launch_one<NESTI_BF16, 128>(p, n_tiles, stream);
-    if (dtype == NESTI_F16) return launch_one<NESTI_F16, 128>(p, n_tiles, stream);
-    if (dtype == NESTI_F32) return launch_one<NESTI_F32, 128>(p, n_tiles, stream);
-  } else if (TN == 64) {
-    if (dtype == NESTI_BF16) return launch_one<NESTI_BF16, 64>(p, n_tiles, stream);
-    if (dtype == NESTI_F16) return launch_one<NESTI_F16, 64>(p, n_tiles, stream);
-    if (dtype == NESTI_F32) return launch_one<NESTI_F32, 64>(p, n_tiles, stream);
-  }
-  NESTI_FAIL("launch_conv: unsupported dtype / tile");
+int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream) {
+  if (p.m_tiles <= 0 || p.n_tiles <= 0) return 0;
+  if (p.pool_k > 1 && p.n_taps != 1) NESTI_FAIL("launch_conv: fused pooling needs a 1x1x1 layer");
+  if (dtype == NESTI_BF16) return launch_dt<NESTI_BF16>(p, TN, stream);
+  if (dtype == NESTI_F16) return launch_dt<NESTI_F16>(p, TN, stream);
+  if (dtype == NESTI_F32) return launch_dt<NESTI_F32>(p, TN, stream);
+  NESTI_FAIL("launch_conv: unsupported dtype");
 }
 
 }  // namespace nesti

@@ -28,11 +28,16 @@ struct ConvParams {
   int n_chunks, n_taps;
   int log2S;           // S in {1,2,4,8}
   int relu, out_f32;
-  int m_tiles;
+  int m_tiles, n_tiles;
+  // merged inception conv1|conv4 launch: column tiles >= split_tile are conv4's; they write at
+  // out_coff2 and average the pre-activation over the pool_k^3 SAME window (pool_k == 1: plain).
+  int split_tile;      // == n_tiles for an ordinary layer
+  int out_coff2;
+  int pool_k;
   int8_t tap[kMaxTaps][4];   // dz, dy, dx, -
 };
 
-int launch_conv(const ConvParams& p, int dtype, int TN, int n_tiles, hipStream_t stream);
+int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream);
 
 struct PoolParams {
   const void* in;

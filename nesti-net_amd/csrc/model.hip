@@ -87,10 +87,12 @@ inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 // ------------------------------------------------------------------------------------------
 struct LayerDesc {
   std::string scope;
+  std::string scope2;        // non-empty: a second 1x1 layer on the same input, fused into this launch
+  int pool_k = 1;            // avg-pool window applied to scope2's pre-activation (conv4 of an inception)
   bool is_fc = false;
   int k = 1;                 // kernel size (1 for fc)
   int log2S = 0;             // spatial size the layer runs at
-  int cin = 0, cout = 0;     // real channel counts (TF variable shapes)
+  int cin = 0, cout = 0;     // real channel counts (TF variable shapes); scope2 has the same shape
   std::vector<int> in_pos;   // real input channel -> position inside the padded input slice
   int Cin_p = 0, Cout_p = 0;
   bool bn = true, relu = true;
@@ -99,15 +101,15 @@ struct LayerDesc {
 struct BufSpec { int log2S; int C; bool f32; };
 
 struct Op {
-  enum Kind { CONV, AVG, MAX } kind;
-  int in_buf = 0, in_coff = 0, out_buf = 0, out_coff = 0;
+  enum Kind { CONV, MAX } kind;
+  int in_buf = 0, in_coff = 0, out_buf = 0, out_coff = 0, out_coff2 = 0;
   int layer = -1;
   int C = 0, k = 0, log2S = 0;
   bool out_f32 = false;
 };
 
 struct Tower {
-  std::vector<BufSpec> bufs;   // bufs[0] = MuPS X0, bufs[1] = avg-pooled MuPS P0 (both external)
+  std::vector<BufSpec> bufs;   // bufs[0] = MuPS X0 (external)
   std::vector<Op> ops;
   int out_buf = -1;            // f32 [NB, 64]
   int n_out = 0;               // real outputs (E or 3)
@@ -130,38 +132,33 @@ struct Builder {
   int add_layer(const LayerDesc& d) { g.layers.push_back(d); return (int)g.layers.size() - 1; }
 
   int conv(Tower& T, const std::string& scope, int k, int log2S, int in_buf, int in_coff, const ChanMap& in,
-           int cout, int out_buf, int out_coff, bool bn = true, bool relu = true, bool fc = false, bool out_f32 = false) {
+           int cout, int out_buf, int out_coff, bool bn = true, bool relu = true, bool fc = false, bool out_f32 = false,
+           const std::string& scope2 = "", int out_coff2 = 0, int pool_k = 1) {
     LayerDesc d;
-    d.scope = scope; d.is_fc = fc; d.k = k; d.log2S = log2S;
+    d.scope = scope; d.scope2 = scope2; d.pool_k = pool_k; d.is_fc = fc; d.k = k; d.log2S = log2S;
     d.cin = (int)in.pos.size(); d.cout = cout; d.in_pos = in.pos; d.Cin_p = in.C;
-    d.Cout_p = pad_to(cout, kPad); d.bn = bn; d.relu = relu;
+    d.Cout_p = pad_to(cout, kPad) * (scope2.empty() ? 1 : 2); d.bn = bn; d.relu = relu;
     Op op; op.kind = Op::CONV; op.in_buf = in_buf; op.in_coff = in_coff; op.out_buf = out_buf; op.out_coff = out_coff;
+    op.out_coff2 = out_coff2;
     op.layer = add_layer(d); op.log2S = log2S; op.out_f32 = out_f32;
     T.ops.push_back(op);
     return d.Cout_p;
   }
 
-  // models/experts_n_est.py:294-314.  pooled_buf < 0: create the avg-pooled copy here.
-  int inception(Tower& T, const std::string& scope, int in_buf, const ChanMap& in, int pooled_buf, int F, int k0,
-                int k1, int log2S, ChanMap* out_map) {
+  // models/experts_n_est.py:294-314.  conv1 and conv4 read the same tensor (avg_pool3d commutes with the
+  // 1x1x1 convolution), so they are one launch; conv4's columns are averaged in the kernel epilogue.
+  int inception(Tower& T, const std::string& scope, int in_buf, const ChanMap& in, int F, int k0, int k1, int log2S,
+                ChanMap* out_map) {
     const int H = F / 2;   // int(n_filters/2)  :299
     const int Fp = pad_to(F, kPad), Hp = pad_to(H, kPad);
     const int C = Fp + Hp + Hp + Fp;
     T.bufs.push_back({log2S, C, false});
     const int ob = (int)T.bufs.size() - 1;
     ChanMap c1; c1.C = Fp; for (int i = 0; i < F; ++i) c1.pos.push_back(i);
-    conv(T, scope + "_conv1", 1, log2S, in_buf, 0, in, F, ob, 0);
+    conv(T, scope + "_conv1", 1, log2S, in_buf, 0, in, F, ob, 0, true, true, false, false,
+         scope + "_conv4", Fp + Hp + Hp, k0);
     conv(T, scope + "_conv2", k0, log2S, ob, 0, c1, H, ob, Fp);
     conv(T, scope + "_conv3", k1, log2S, ob, 0, c1, H, ob, Fp + Hp);
-    int pb = pooled_buf;
-    if (k0 == 1) pb = in_buf;   // avg_pool3d with a 1^3 window is the identity (:307)
-    else if (pb < 0) {
-      T.bufs.push_back({log2S, in.C, false});
-      pb = (int)T.bufs.size() - 1;
-      Op op; op.kind = Op::AVG; op.in_buf = in_buf; op.out_buf = pb; op.C = in.C; op.k = k0; op.log2S = log2S;
-      T.ops.push_back(op);
-    }
-    conv(T, scope + "_conv4", 1, log2S, pb, 0, in, F, ob, Fp + Hp + Hp);
     out_map->pos.clear();
     for (int i = 0; i < F; ++i) out_map->pos.push_back(i);
     for (int i = 0; i < H; ++i) out_map->pos.push_back(Fp + i);
@@ -200,7 +197,6 @@ struct Builder {
   void init_tower(Tower& T) {
     T.bufs.clear(); T.ops.clear();
     T.bufs.push_back({3, g.mups_cstride, false});   // 0: X0
-    T.bufs.push_back({3, g.mups_cstride, false});   // 1: P0 = avg_pool3(X0)
   }
 
   // scale_manager_net + conv_net_8g (models/experts_n_est.py:155-215)
@@ -211,14 +207,14 @@ struct Builder {
     ChanMap m; m.C = g.mups_cstride;
     for (int c = 0; c < 20 * S; ++c) m.pos.push_back(c);
     const std::string s = "gating_conv";
-    int b = inception(T, "inception1" + s, 0, m, 1, 128, 3, 5, 3, &m);
-    b = inception(T, "inception2" + s, b, m, -1, 256, 3, 5, 3, &m);
-    b = inception(T, "inception3" + s, b, m, -1, 256, 3, 5, 3, &m);
+    int b = inception(T, "inception1" + s, 0, m, 128, 3, 5, 3, &m);
+    b = inception(T, "inception2" + s, b, m, 256, 3, 5, 3, &m);
+    b = inception(T, "inception3" + s, b, m, 256, 3, 5, 3, &m);
     b = maxpool(T, b, m, 3);
-    b = inception(T, "inception5" + s, b, m, -1, 512, 2, 4, 2, &m);
-    b = inception(T, "inception6" + s, b, m, -1, 512, 2, 4, 2, &m);
+    b = inception(T, "inception5" + s, b, m, 512, 2, 4, 2, &m);
+    b = inception(T, "inception6" + s, b, m, 512, 2, 4, 2, &m);
     b = maxpool(T, b, m, 2);
-    b = inception(T, "inception8" + s, b, m, -1, 512, 1, 2, 1, &m);
+    b = inception(T, "inception8" + s, b, m, 512, 1, 2, 1, &m);
     b = maxpool(T, b, m, 1);
     T.out_buf = fc_stack(T, b, m, {"fc1noise", "fc2noise", "fc3noise", "fc4noise"}, {1024, 256, 128, g.cfg.n_experts},
                          /*last_relu=*/true);   // relu on fc4: models/experts_n_est.py:174
@@ -234,12 +230,12 @@ struct Builder {
     for (int c = 0; c < 20 * cnt; ++c) m.pos.push_back(20 * lo + c);   // MuPS[..., start:end]  :100-102
     const std::string s = "Expert_" + std::to_string(i);
     const int F1 = 128 / cnt;   // np.round(128 / divider) under Python-2 integer division  :254
-    int b = inception(T, "inception1" + s, 0, m, 1, F1, 3, 5, 3, &m);
-    b = inception(T, "inception2" + s, b, m, -1, 256, 3, 5, 3, &m);
+    int b = inception(T, "inception1" + s, 0, m, F1, 3, 5, 3, &m);
+    b = inception(T, "inception2" + s, b, m, 256, 3, 5, 3, &m);
     b = maxpool(T, b, m, 3);
-    b = inception(T, "inception4" + s, b, m, -1, 256, 2, 4, 2, &m);
+    b = inception(T, "inception4" + s, b, m, 256, 2, 4, 2, &m);
     b = maxpool(T, b, m, 2);
-    b = inception(T, "inception6" + s, b, m, -1, 512, 2, 4, 1, &m);
+    b = inception(T, "inception6" + s, b, m, 512, 2, 4, 1, &m);
     b = maxpool(T, b, m, 1);
     T.out_buf = fc_stack(T, b, m, {"fc1" + s, "fc2" + s, "fc3" + s, "fc4" + s}, {512, 128, 64, 3}, /*last_relu=*/false);
     T.n_out = 3;
@@ -272,7 +268,7 @@ int build_graph(const nesti_config_t* cfg, Graph* g) {
 struct PackedLayer {
   void* wpk = nullptr;
   float* bias = nullptr;
-  int TN = 64, n_tiles = 0, n_chunks = 0, n_taps = 0;
+  int TN = 64, n_tiles = 0, split_tile = 0, n_chunks = 0, n_taps = 0;
   int8_t tap[kMaxTaps][4];
 };
 
@@ -311,36 +307,56 @@ bool shape_is(const nesti_tensor_t* t, std::initializer_list<int64_t> dims) {
 
 // Expected variables of one layer, in TF naming (utils/tf_util.py:289-302, 332-342, 473-479).
 void layer_tensors(const LayerDesc& d, std::vector<std::pair<std::string, std::vector<int64_t>>>* out) {
-  if (d.is_fc) out->push_back({d.scope + "/weights", {d.cin, d.cout}});
-  else out->push_back({d.scope + "/weights", {d.k, d.k, d.k, d.cin, d.cout}});
-  out->push_back({d.scope + "/biases", {d.cout}});
-  if (d.bn) {
-    for (const char* n : {"beta", "gamma", "mean", "var"}) out->push_back({d.scope + "/bn/" + n, {d.cout}});
+  for (const std::string* sc : {&d.scope, &d.scope2}) {
+    if (sc->empty()) continue;
+    if (d.is_fc) out->push_back({*sc + "/weights", {d.cin, d.cout}});
+    else out->push_back({*sc + "/weights", {d.k, d.k, d.k, d.cin, d.cout}});
+    out->push_back({*sc + "/biases", {d.cout}});
+    if (d.bn) {
+      for (const char* n : {"beta", "gamma", "mean", "var"}) out->push_back({*sc + "/bn/" + n, {d.cout}});
+    }
   }
 }
 
-int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer* pl) {
-  const nesti_tensor_t* w = tt.get(d.scope + "/weights");
-  const nesti_tensor_t* b = tt.get(d.scope + "/biases");
+// BN-folded weights/bias of one TF layer (utils/tf_util.py:298-311, 491-494)
+struct Folded {
+  const float* w = nullptr;        // [taps][cin][cout]
+  std::vector<float> scale, bias;  // per real output channel
+};
+
+int fold_layer(const LayerDesc& d, const std::string& scope, const TensorTable& tt, Folded* f) {
+  const nesti_tensor_t* w = tt.get(scope + "/weights");
+  const nesti_tensor_t* b = tt.get(scope + "/biases");
   const bool wok = d.is_fc ? shape_is(w, {d.cin, d.cout}) : shape_is(w, {d.k, d.k, d.k, d.cin, d.cout});
-  if (!wok) NESTI_FAIL("missing or mis-shaped tensor " + d.scope + "/weights");
-  if (!shape_is(b, {d.cout})) NESTI_FAIL("missing or mis-shaped tensor " + d.scope + "/biases");
-  std::vector<float> scale(d.cout, 1.0f), bias(d.cout);
-  for (int n = 0; n < d.cout; ++n) bias[n] = b->data[n];
+  if (!wok) NESTI_FAIL("missing or mis-shaped tensor " + scope + "/weights");
+  if (!shape_is(b, {d.cout})) NESTI_FAIL("missing or mis-shaped tensor " + scope + "/biases");
+  f->w = w->data;
+  f->scale.assign(d.cout, 1.0f);
+  f->bias.resize(d.cout);
+  for (int n = 0; n < d.cout; ++n) f->bias[n] = b->data[n];
   if (d.bn) {
-    const nesti_tensor_t* beta = tt.get(d.scope + "/bn/beta");
-    const nesti_tensor_t* gamma = tt.get(d.scope + "/bn/gamma");
-    const nesti_tensor_t* mean = tt.get(d.scope + "/bn/mean");
-    const nesti_tensor_t* var = tt.get(d.scope + "/bn/var");
+    const nesti_tensor_t* beta = tt.get(scope + "/bn/beta");
+    const nesti_tensor_t* gamma = tt.get(scope + "/bn/gamma");
+    const nesti_tensor_t* mean = tt.get(scope + "/bn/mean");
+    const nesti_tensor_t* var = tt.get(scope + "/bn/var");
     if (!shape_is(beta, {d.cout}) || !shape_is(gamma, {d.cout}) || !shape_is(mean, {d.cout}) || !shape_is(var, {d.cout}))
-      NESTI_FAIL("missing or mis-shaped batch-norm tensors under " + d.scope + "/bn/");
+      NESTI_FAIL("missing or mis-shaped batch-norm tensors under " + scope + "/bn/");
     for (int n = 0; n < d.cout; ++n) {
       // tf.nn.batch_normalization(x, mean, var, beta, gamma, 1e-3)  (utils/tf_util.py:494)
       const double inv = (double)gamma->data[n] / sqrt((double)var->data[n] + 1e-3);
-      scale[n] = (float)inv;
-      bias[n] = (float)(((double)b->data[n] - (double)mean->data[n]) * inv + (double)beta->data[n]);
+      f->scale[n] = (float)inv;
+      f->bias[n] = (float)(((double)b->data[n] - (double)mean->data[n]) * inv + (double)beta->data[n]);
     }
   }
+  return 0;
+}
+
+int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer* pl) {
+  const int n_parts = d.scope2.empty() ? 1 : 2;
+  Folded parts[2];
+  if (fold_layer(d, d.scope, tt, &parts[0])) return 1;
+  if (n_parts == 2 && fold_layer(d, d.scope2, tt, &parts[1])) return 1;
+  const int part_p = d.Cout_p / n_parts;   // padded width of one part
   const int S = 1 << d.log2S;
   const int lo = (d.k - 1) / 2;   // TF SAME, stride 1
   pl->n_taps = 0;
@@ -357,30 +373,36 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
       }
   const int KC = chunk_elems(dtype);
   const size_t esz = dtype_size(dtype);
-  pl->TN = (d.Cout_p % 128 == 0) ? 128 : 64;
+  pl->TN = (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
   pl->n_tiles = d.Cout_p / pl->TN;
+  pl->split_tile = part_p / pl->TN * (n_parts == 2 ? 1 : n_parts);
+  if (n_parts == 1) pl->split_tile = pl->n_tiles;
   pl->n_chunks = d.Cin_p / KC;
   if (d.Cin_p % KC) NESTI_FAIL("internal: Cin_p not a multiple of the K chunk");
+  if (n_parts == 2 && pl->n_taps != 1) NESTI_FAIL("internal: fused layers must be 1x1x1");
   std::vector<int> inv(d.Cin_p, -1);
   for (int c = 0; c < d.cin; ++c) inv[d.in_pos[c]] = c;
   const size_t tile_bytes = (size_t)pl->TN * kRowBytes;
   const size_t total = (size_t)pl->n_tiles * pl->n_chunks * pl->n_taps * tile_bytes;
   std::vector<unsigned char> host(total, 0);
   const int per_slot = 16 / (int)esz;
-  for (int nt = 0; nt < pl->n_tiles; ++nt)
+  for (int nt = 0; nt < pl->n_tiles; ++nt) {
+    const int part = (nt * pl->TN) / part_p;
+    const int n_base = nt * pl->TN - part * part_p;    // first real channel of this tile within its part
+    const Folded& f = parts[part];
     for (int ch = 0; ch < pl->n_chunks; ++ch)
       for (int t = 0; t < pl->n_taps; ++t) {
         unsigned char* tile = host.data() + (((size_t)nt * pl->n_chunks + ch) * pl->n_taps + t) * tile_bytes;
-        const float* wt = w->data + (size_t)tap_widx[t] * d.cin * d.cout;
+        const float* wt = f.w + (size_t)tap_widx[t] * d.cin * d.cout;
         for (int kc = 0; kc < KC; ++kc) {
           const int cr = inv[ch * KC + kc];
           if (cr < 0) continue;
           const float* wrow = wt + (size_t)cr * d.cout;
           const int slot = kc / per_slot, within = kc % per_slot;
           for (int nl = 0; nl < pl->TN; ++nl) {
-            const int n = nt * pl->TN + nl;
+            const int n = n_base + nl;
             if (n >= d.cout) break;
-            const float v = wrow[n] * scale[n];
+            const float v = wrow[n] * f.scale[n];
             unsigned char* dst = tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
             if (dtype == NESTI_F32) memcpy(dst, &v, 4);
             else {
@@ -390,8 +412,10 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
           }
         }
       }
+  }
   std::vector<float> bias_p((size_t)pl->n_tiles * pl->TN, 0.f);
-  for (int n = 0; n < d.cout; ++n) bias_p[n] = bias[n];
+  for (int part = 0; part < n_parts; ++part)
+    for (int n = 0; n < d.cout; ++n) bias_p[(size_t)part * part_p + n] = parts[part].bias[n];
   NESTI_CHECK_HIP(hipMalloc(&pl->wpk, total));
   NESTI_CHECK_HIP(hipMemcpy(pl->wpk, host.data(), total, hipMemcpyHostToDevice));
   NESTI_CHECK_HIP(hipMalloc((void**)&pl->bias, bias_p.size() * sizeof(float)));
@@ -408,7 +432,7 @@ size_t buf_bytes(const BufSpec& b, int NB, int dtype) {
 }
 size_t tower_bytes(const Tower& T, int NB, int dtype) {
   size_t s = 0;
-  for (size_t i = 2; i < T.bufs.size(); ++i) s += buf_bytes(T.bufs[i], NB, dtype);
+  for (size_t i = 1; i < T.bufs.size(); ++i) s += buf_bytes(T.bufs[i], NB, dtype);
   return s;
 }
 
@@ -420,20 +444,18 @@ struct RunCtx {
   hipStream_t stream;
 };
 
-int run_tower(const RunCtx& rc, const Tower& T, const void* X0, const void* P0, unsigned char* ws, size_t ws_bytes,
-              float** out) {
+int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* ws, size_t ws_bytes, float** out) {
   const int dtype = rc.m->dtype;
   std::vector<unsigned char*> ptr(T.bufs.size(), nullptr);
   ptr[0] = (unsigned char*)X0;
-  ptr[1] = (unsigned char*)P0;
   size_t off = 0;
-  for (size_t i = 2; i < T.bufs.size(); ++i) {
+  for (size_t i = 1; i < T.bufs.size(); ++i) {
     ptr[i] = ws + off;
     off += buf_bytes(T.bufs[i], rc.NB, dtype);
   }
   if (off > ws_bytes) NESTI_FAIL("workspace too small for this batch");
   for (const Op& op : T.ops) {
-    const bool ext_in = op.in_buf < 2;
+    const bool ext_in = op.in_buf < 1;
     if (op.kind == Op::CONV) {
       const LayerDesc& d = rc.m->graph.layers[op.layer];
       const PackedLayer& pl = rc.m->packed[op.layer];
@@ -448,9 +470,10 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, const void* P0, 
       p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
       const long long rows = (long long)rc.NB << (3 * d.log2S);
       p.m_tiles = (int)((rows + kTileM - 1) / kTileM);
+      p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       prof_begin(NESTI_PROF_CONV, rc.stream);
-      const int rcv = launch_conv(p, dtype, pl.TN, pl.n_tiles, rc.stream);
+      const int rcv = launch_conv(p, dtype, pl.TN, rc.stream);
       prof_end(NESTI_PROF_CONV, rc.stream);
       if (rcv) return 1;
     } else {
@@ -463,26 +486,13 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, const void* P0, 
       p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
       p.C = op.C; p.log2S = op.log2S; p.k = op.k;
       prof_begin(NESTI_PROF_POOL, rc.stream);
-      const int rcp = (op.kind == Op::AVG) ? launch_avgpool(p, dtype, rc.stream) : launch_maxpool2(p, dtype, rc.stream);
+      const int rcp = launch_maxpool2(p, dtype, rc.stream);
       prof_end(NESTI_PROF_POOL, rc.stream);
       if (rcp) return 1;
     }
   }
   *out = reinterpret_cast<float*>(ptr[T.out_buf]);
   return 0;
-}
-
-// avg_pool3d(MuPS, 3^3): shared by the gate's and every expert's first inception (their input and k0 coincide)
-int pool_mups(const nesti_model* m, const void* X0, void* P0, int B, hipStream_t stream) {
-  PoolParams p;
-  memset(&p, 0, sizeof(p));
-  p.in = X0; p.out = P0; p.npoints = B;
-  p.in_cstride = p.out_cstride = p.C = m->graph.mups_cstride;
-  p.log2S = 3; p.k = 3;
-  prof_begin(NESTI_PROF_POOL, stream);
-  const int rc = launch_avgpool(p, m->dtype, stream);
-  prof_end(NESTI_PROF_POOL, stream);
-  return rc;
 }
 
 size_t max_tower_bytes(const nesti_model* m, int NB) {
@@ -492,14 +502,13 @@ size_t max_tower_bytes(const nesti_model* m, int NB) {
 }
 
 struct WsLayout {
-  size_t x0, p0, probs, expert, counts, lists, tower, total;
+  size_t x0, probs, expert, counts, lists, tower, total;
 };
 WsLayout ws_layout(const nesti_model* m, int NB) {
   WsLayout L;
   const size_t act = align_up(((size_t)NB << 9) * m->graph.mups_cstride * dtype_size(m->dtype), 256);
   size_t o = 0;
   L.x0 = o; o += act;
-  L.p0 = o; o += act;
   L.probs = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
   L.expert = o; o += align_up((size_t)NB * 4, 256);
   L.counts = o; o += 256;
@@ -509,16 +518,16 @@ WsLayout ws_layout(const nesti_model* m, int NB) {
   return L;
 }
 
-int gate_impl(const nesti_model* m, const void* X0, const void* P0, int B, unsigned char* tower_ws, size_t tower_bytes_,
+int gate_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_ws, size_t tower_bytes_,
               float* probs, int32_t* expert, int32_t* counts, int32_t* lists, hipStream_t stream) {
   RunCtx rc{m, B, nullptr, nullptr, stream};
   float* logits = nullptr;
-  if (run_tower(rc, m->graph.gate, X0, P0, tower_ws, tower_bytes_, &logits)) return 1;
+  if (run_tower(rc, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
   const int lstride = m->graph.gate.bufs[m->graph.gate.out_buf].C;
   return launch_gate_finish(logits, lstride, B, m->graph.cfg.n_experts, probs, expert, counts, lists, stream);
 }
 
-int experts_impl(const nesti_model* m, const void* X0, const void* P0, int B, unsigned char* tower_ws, size_t tower_bytes_,
+int experts_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_ws, size_t tower_bytes_,
                  const int32_t* counts, const int32_t* lists, float* normals, hipStream_t stream) {
   const int E = m->graph.cfg.n_experts;
   for (int e = 0; e < E; ++e) {
@@ -527,11 +536,11 @@ int experts_impl(const nesti_model* m, const void* X0, const void* P0, int B, un
     const int ostride = T.bufs[T.out_buf].C;
     if (counts) {   // top-1 routing: only the points whose arg-max is e (test_n_est_w_experts.py:150-152)
       RunCtx rc{m, B, counts + e, lists + (size_t)e * B, stream};
-      if (run_tower(rc, T, X0, P0, tower_ws, tower_bytes_, &out)) return 1;
+      if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
       if (launch_scatter3(out, ostride, lists + (size_t)e * B, counts + e, B, normals, stream)) return 1;
     } else {        // reference behaviour: every expert on every point -> [E,B,3]
       RunCtx rc{m, B, nullptr, nullptr, stream};
-      if (run_tower(rc, T, X0, P0, tower_ws, tower_bytes_, &out)) return 1;
+      if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
       if (launch_scatter3(out, ostride, nullptr, nullptr, B, normals + (size_t)e * B * 3, stream)) return 1;
     }
   }
@@ -649,8 +658,7 @@ int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void
   if (L.total > ws_bytes) NESTI_FAIL("nesti_gate_forward: workspace too small (see nesti_workspace_bytes)");
   unsigned char* ws = (unsigned char*)ws_dev;
   hipStream_t st = (hipStream_t)stream;
-  if (pool_mups(m, mups_dev, ws + L.p0, B, st)) return 1;
-  return gate_impl(m, mups_dev, ws + L.p0, B, ws + L.tower, L.total - L.tower, probs_out_dev, expert_out_dev, nullptr,
+  return gate_impl(m, mups_dev, B, ws + L.tower, L.total - L.tower, probs_out_dev, expert_out_dev, nullptr,
                    nullptr, st);
 }
 
@@ -662,7 +670,6 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
   if (L.total > ws_bytes) NESTI_FAIL("nesti_experts_forward: workspace too small (see nesti_workspace_bytes)");
   unsigned char* ws = (unsigned char*)ws_dev;
   hipStream_t st = (hipStream_t)stream;
-  if (pool_mups(m, mups_dev, ws + L.p0, B, st)) return 1;
   int32_t* counts = nullptr;
   int32_t* lists = nullptr;
   if (expert_dev) {
@@ -670,7 +677,7 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
     lists = (int32_t*)(ws + L.lists);
     if (launch_route(expert_dev, B, m->graph.cfg.n_experts, counts, lists, st)) return 1;
   }
-  return experts_impl(m, mups_dev, ws + L.p0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
+  return experts_impl(m, mups_dev, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
 }
 
 int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B, void* ws_dev,
@@ -682,18 +689,16 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   unsigned char* ws = (unsigned char*)ws_dev;
   hipStream_t st = (hipStream_t)stream;
   void* X0 = ws + L.x0;
-  void* P0 = ws + L.p0;
   prof_begin(NESTI_PROF_MUPS, st);
   const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride, st);
   prof_end(NESTI_PROF_MUPS, st);
   if (rcm) return 1;
-  if (pool_mups(m, X0, P0, B, st)) return 1;
   float* probs = probs_out_dev ? probs_out_dev : (float*)(ws + L.probs);
   int32_t* expert = expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert);
   int32_t* counts = (int32_t*)(ws + L.counts);
   int32_t* lists = (int32_t*)(ws + L.lists);
-  if (gate_impl(m, X0, P0, B, ws + L.tower, L.total - L.tower, probs, expert, counts, lists, st)) return 1;
-  return experts_impl(m, X0, P0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
+  if (gate_impl(m, X0, B, ws + L.tower, L.total - L.tower, probs, expert, counts, lists, st)) return 1;
+  return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
 }
 
 int nesti_profile_enable(int on) {
@@ -729,8 +734,9 @@ int nesti_model_macs(const nesti_model_t* m, int tower, double* nominal, double*
         const int zz = z + a - lo, yy = y + b - lo, xx = x + c - lo;
         if (zz >= 0 && zz < S && yy >= 0 && yy < S && xx >= 0 && xx < S) ++valid;
       }
-    nom += (double)V * d.k * d.k * d.k * d.cin * d.cout;
-    use += (double)valid * d.cin * d.cout;
+    const int parts = d.scope2.empty() ? 1 : 2;
+    nom += (double)parts * V * d.k * d.k * d.k * d.cin * d.cout;
+    use += (double)parts * valid * d.cin * d.cout;
     iss += (double)V * pl.n_taps * d.Cin_p * d.Cout_p;
   }
   if (nominal) *nominal = nom;
