@@ -126,13 +126,13 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
       reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)n_tile * p.n_chunks * p.n_taps * kBTile;
 
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic segment
-  auto stage_a = [&](int c, int a_buf) {
+  auto stage_a = [&](int c, int a_buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (a_off[j] >= 0)
         glds16(in_b + a_off[j] + (long long)c * kRowBytes, lds0 + a_buf * kABytes + (wave * 8 + j) * 1024);
   };
-  auto stage_b = [&](int c, int t, int b_buf) {
+  auto stage_b = [&](int c, int t, int b_buf) __attribute__((always_inline)) {
     const unsigned char* src = w_tile + ((size_t)c * p.n_taps + t) * kBTile;
 #pragma unroll
     for (int q = 0; q < kBVec; ++q) {
@@ -164,7 +164,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   // one (chunk, tap) step: 4 K-steps of 2 x NI MFMAs
-  auto compute = [&](const unsigned char* Acur, const unsigned char* Bcur, const int (&a_addr)[2], const int (&a_sw)[2]) {
+  auto compute = [&](const unsigned char* Acur, const unsigned char* Bcur, const int (&a_addr)[2],
+                     const int (&a_sw)[2]) __attribute__((always_inline)) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int slot = kk * 2 + khalf;
@@ -242,10 +243,81 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   const float* bias = p.bias + n_tile * TN;
 
   if (KPIPE && second && p.pool_k > 1) {
-    // avg_pool3d(k, SAME, stride 1) of the pre-activation, per 64-column half, through an fp32 LDS tile
-    const int lo = (p.pool_k - 1) / 2;
+    // avg_pool3d(k, SAME, stride 1) of the pre-activation: per 64-column half the fp32 accumulators go
+    // through an LDS tile [512][64 (+4 pad)]; a thread then owns whole x-lines of one 4-channel group, loads
+    // each of the K^2 neighbouring lines once (an out-of-volume line reads a zero row) and forms all S
+    // windowed sums from registers.  S and K are compile-time so every load is independent.
+    unsigned char* const zero16 = smem + kTileM * kPoolStride;
+    if (tid < 4) reinterpret_cast<uint32_t*>(zero16)[tid] = 0u;
+    auto pool_lines = [&](auto SS, auto KK, int nh) __attribute__((always_inline)) {
+      constexpr int S_ = decltype(SS)::value, K_ = decltype(KK)::value;
+      constexpr int lo = (K_ - 1) / 2;
+      constexpr int log2S_ = (S_ == 8) ? 3 : (S_ == 4) ? 2 : 1;
+#pragma unroll 1
+      for (int it = 0; it < 16 / S_; ++it) {
+        const int item = it * kThreads + tid;
+        const int line = item >> 4, cg = item & 15;
+        const int y = line & (S_ - 1), z = (line >> log2S_) & (S_ - 1);
+        const int row0 = line << log2S_;
+        float4 sum[S_];
+#pragma unroll
+        for (int x = 0; x < S_; ++x) sum[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int nz = 0, ny = 0;
+#pragma unroll
+        for (int a = 0; a < K_; ++a) nz += ((unsigned)(z + a - lo) < (unsigned)S_) ? 1 : 0;
+#pragma unroll
+        for (int b = 0; b < K_; ++b) ny += ((unsigned)(y + b - lo) < (unsigned)S_) ? 1 : 0;
+#pragma unroll 1   // keep at most K lines x S loads in flight: full unrolling spills
+        for (int a = 0; a < K_; ++a) {
+#pragma unroll
+          for (int b = 0; b < K_; ++b) {
+            const bool ok = ((unsigned)(z + a - lo) < (unsigned)S_) & ((unsigned)(y + b - lo) < (unsigned)S_);
+            const int nrow0 = row0 + (((a - lo) * S_ + (b - lo)) << log2S_);
+            const unsigned char* base = ok ? smem + nrow0 * kPoolStride + cg * 16 : zero16;
+            const int stride = ok ? kPoolStride : 0;
+            float4 v[S_];
+#pragma unroll
+            for (int x = 0; x < S_; ++x) v[x] = *reinterpret_cast<const float4*>(base + x * stride);
+#pragma unroll
+            for (int x = 0; x < S_; ++x) {
+#pragma unroll
+              for (int c = 0; c < K_; ++c) {
+                constexpr int dummy = 0; (void)dummy;
+                const int xx = x + c - lo;
+                if (xx >= 0 && xx < S_) { sum[x].x += v[xx].x; sum[x].y += v[xx].y; sum[x].z += v[xx].z; sum[x].w += v[xx].w; }
+              }
+            }
+          }
+        }
+        const float4 bb = *reinterpret_cast<const float4*>(bias + nh * 64 + cg * 4);
+#pragma unroll
+        for (int x = 0; x < S_; ++x) {
+          int nx = 0;
+#pragma unroll
+          for (int c = 0; c < K_; ++c) nx += (x + c - lo >= 0 && x + c - lo < S_) ? 1 : 0;
+          const float inv = 1.0f / (float)(nz * ny * nx);      // taps inside the volume (utils/tf_util.py:450-454)
+          float o[4] = {sum[x].x * inv + bb.x, sum[x].y * inv + bb.y, sum[x].z * inv + bb.z, sum[x].w * inv + bb.w};
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+          }
+          const long long gr = r0 + row0 + x;
+          if (gr < total_rows) {
+            unsigned char* dst = out_b + (gr * p.out_cstride + out_col0 + nh * 64 + cg * 4) * out_esz;
+            if (out_esz == 4) {
+              *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+              using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
+              const uint32_t w0 = (uint32_t)E::from_f32(o[0]) | ((uint32_t)E::from_f32(o[1]) << 16);
+              const uint32_t w1 = (uint32_t)E::from_f32(o[2]) | ((uint32_t)E::from_f32(o[3]) << 16);
+              *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
+            }
+          }
+        }
+      }
+    };
     // one call per 64-column half with a compile-time index: runtime-indexed register arrays go to scratch
-    auto pool_half = [&](auto NH) {
+    auto pool_half = [&](auto NH) __attribute__((always_inline)) {
       constexpr int nh = decltype(NH)::value;
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -260,50 +332,9 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           }
         }
       __syncthreads();
-#pragma unroll 1
-      for (int it = 0; it < 16; ++it) {
-        const int item = it * kThreads + tid;
-        const int row = item >> 4, cg = item & 15;
-        const int vox = row & (V - 1);
-        const int z = vox >> (2 * log2S), y = (vox >> log2S) & (S - 1), x = vox & (S - 1);
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        int cnt = 0;
-        for (int a = 0; a < p.pool_k; ++a) {
-          const int zz = z + a - lo;
-          if ((unsigned)zz >= (unsigned)S) continue;
-          for (int b = 0; b < p.pool_k; ++b) {
-            const int yy = y + b - lo;
-            if ((unsigned)yy >= (unsigned)S) continue;
-            for (int c = 0; c < p.pool_k; ++c) {
-              const int xx = x + c - lo;
-              if ((unsigned)xx >= (unsigned)S) continue;
-              const int nrow = row + ((zz - z) << (2 * log2S)) + ((yy - y) << log2S) + (xx - x);
-              const float4 v = *reinterpret_cast<const float4*>(smem + nrow * kPoolStride + cg * 16);
-              s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-              ++cnt;
-            }
-          }
-        }
-        const float inv = 1.0f / (float)cnt;
-        const float4 bb = *reinterpret_cast<const float4*>(bias + nh * 64 + cg * 4);
-        float o[4] = {s.x * inv + bb.x, s.y * inv + bb.y, s.z * inv + bb.z, s.w * inv + bb.w};
-        if (p.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-        }
-        const long long gr = r0 + row;
-        if (gr < total_rows) {
-          unsigned char* dst = out_b + (gr * p.out_cstride + out_col0 + nh * 64 + cg * 4) * out_esz;
-          if (out_esz == 4) {
-            *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-          } else {
-            using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
-            const uint32_t w0 = (uint32_t)E::from_f32(o[0]) | ((uint32_t)E::from_f32(o[1]) << 16);
-            const uint32_t w1 = (uint32_t)E::from_f32(o[2]) | ((uint32_t)E::from_f32(o[3]) << 16);
-            *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
-          }
-        }
-      }
+      if (log2S == 3 && p.pool_k == 3) pool_lines(std::integral_constant<int, 8>{}, std::integral_constant<int, 3>{}, nh);
+      else if (log2S == 2 && p.pool_k == 2) pool_lines(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, nh);
+      else if (log2S == 1 && p.pool_k == 2) pool_lines(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, nh);
       __syncthreads();
     };
     pool_half(std::integral_constant<int, 0>{});
@@ -357,7 +388,7 @@ int launch_one(const ConvParams& p, hipStream_t stream) {
   static bool attr_set = false;
   constexpr size_t lds = lds_bytes<TN, KPIPE>();
   static_assert(lds <= 163840, "LDS budget");
-  static_assert(!KPIPE || lds >= (size_t)kTileM * kPoolStride, "pooling tile must fit");
+  static_assert(!KPIPE || lds >= (size_t)kTileM * kPoolStride + 16, "pooling tile + zero slot must fit");
   if (!attr_set) {
     NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN, KPIPE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -383,6 +414,8 @@ int launch_dt(const ConvParams& p, int TN, hipStream_t stream) {
 int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream) {
   if (p.m_tiles <= 0 || p.n_tiles <= 0) return 0;
   if (p.pool_k > 1 && p.n_taps != 1) NESTI_FAIL("launch_conv: fused pooling needs a 1x1x1 layer");
+  if (p.pool_k > 1 && !((p.log2S == 3 && p.pool_k == 3) || (p.log2S == 2 && p.pool_k == 2) || (p.log2S == 1 && p.pool_k == 2)))
+    NESTI_FAIL("launch_conv: fused pooling supports (S,k) in {(8,3),(4,2),(2,2)}");
   if (dtype == NESTI_BF16) return launch_dt<NESTI_BF16>(p, TN, stream);
   if (dtype == NESTI_F16) return launch_dt<NESTI_F16>(p, TN, stream);
   if (dtype == NESTI_F32) return launch_dt<NESTI_F32>(p, TN, stream);
