@@ -14,8 +14,8 @@
 //   N tile  = TN (64 or 128) output channels;
 //   K loop  = input-channel chunks (128 bytes per row: 64 x bf16/f16 or 32 x f32) outer,
 //             taps inner; per (chunk, tap) a TN x 128 B weight tile streams from L2 straight
-//             into a double-buffered LDS slot (global_load_lds, no VGPR round trip) while the
-//             current tap's MFMAs run;
+//             into one of 4 LDS slots (global_load_lds, no VGPR round trip) while the current
+//             taps' MFMAs run; two taps per barrier;
 //   wave w  = rows [64w, 64w+64) x all TN columns: 2 x (TN/32) tiles of 32x32, fp32 accumulate.
 // LDS rows are 128 B with the 16-B slot index XOR-swizzled by (row>>1)&7 (applied on the global
 // SOURCE address, since global_load_lds writes lane-linear), which makes the ds_read_b128
@@ -86,7 +86,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   constexpr int kNA = KPIPE ? 2 : 1;              // A buffers
   unsigned char* As = smem;
   unsigned char* Bs = smem + kNA * kABytes;
-  constexpr int kZeroOff = kNA * kABytes + 2 * kBTile;   // all-zero 128-B row (general variant only)
+  constexpr int kNB = KPIPE ? 2 : 4;              // weight-tile slots (general variant: 2 groups of 2 taps)
+  constexpr int kZeroOff = kNA * kABytes + kNB * kBTile;   // all-zero 128-B row (general variant only)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -163,23 +164,29 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  // one (chunk, tap) step: 4 K-steps of 2 x NI MFMAs
+  // one (chunk, tap) step: 4 K-steps of 2 x NI MFMAs; the fragments of K-step kk+1 are read from LDS
+  // before the MFMAs of K-step kk are issued, so the LDS latency hides behind the matrix pipe.
   auto compute = [&](const unsigned char* Acur, const unsigned char* Bcur, const int (&a_addr)[2],
                      const int (&a_sw)[2]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    uint4 a[2][2], b[2][NI];
+    auto load_frags = [&](int kk, uint4 (&af)[2], uint4 (&bf)[NI]) __attribute__((always_inline)) {
       const int slot = kk * 2 + khalf;
-      uint4 a[2], b[NI];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
-        a[mi] = *reinterpret_cast<const uint4*>(Acur + a_addr[mi] + ((slot ^ a_sw[mi]) << 4));
+        af[mi] = *reinterpret_cast<const uint4*>(Acur + a_addr[mi] + ((slot ^ a_sw[mi]) << 4));
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        b[ni] = *reinterpret_cast<const uint4*>(Bcur + ni * 32 * kRowBytes + b_row + ((slot ^ b_sw) << 4));
+        bf[ni] = *reinterpret_cast<const uint4*>(Bcur + ni * 32 * kRowBytes + b_row + ((slot ^ b_sw) << 4));
+    };
+    load_frags(0, a[0], b[0]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 3) load_frags(kk + 1, a[(kk + 1) & 1], b[(kk + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this K-step's MFMAs (hipcc sinks it otherwise)
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[mi][ni], a[mi], b[ni]);
+        for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[mi][ni], a[kk & 1][mi], b[kk & 1][ni]);
     }
   };
 
@@ -209,25 +216,38 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
       __syncthreads();   // every wave is done with the previous chunk's tiles
       stage_a(c, 0);
       stage_b(c, 0, 0);
+      if (p.n_taps > 1) stage_b(c, 1, 1);
       wait_vm0();
       __syncthreads();
-      for (int t = 0; t < p.n_taps; ++t) {
-        if (t + 1 < p.n_taps) stage_b(c, t + 1, (t + 1) & 1);
-        const int dz = p.tap[t][0], dy = p.tap[t][1], dx = p.tap[t][2];
-        const int shift = dz * (1 << (2 * log2S)) + dy * S + dx;
-        int a_addr[2], a_sw[2];
-        bool any_ok = false;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const bool ok = ((unsigned)(rz[mi] + dz) < (unsigned)S) & ((unsigned)(ry[mi] + dy) < (unsigned)S) &
-                          ((unsigned)(rx[mi] + dx) < (unsigned)S);
-          const int srow = rrow[mi] + shift;
-          a_addr[mi] = ok ? srow * kRowBytes : kZeroOff;   // padding tap -> the zero row
-          a_sw[mi] = ok ? ((srow >> 1) & 7) : 0;
-          any_ok |= ok;
+      // two taps per barrier: group g = step & 1 holds the weight tiles of taps 2*step and 2*step+1
+      const int n_steps = (p.n_taps + 1) >> 1;
+      for (int st = 0; st < n_steps; ++st) {
+        const int grp_cur = st & 1;
+        if (st + 1 < n_steps) {
+          const int t2 = 2 * (st + 1);
+          stage_b(c, t2, (grp_cur ^ 1) * 2);
+          if (t2 + 1 < p.n_taps) stage_b(c, t2 + 1, (grp_cur ^ 1) * 2 + 1);
         }
-        if (__ballot(any_ok) != 0ull)   // a whole-wave padding tap (z-plane halo) issues no MFMAs
-          compute(As, Bs + (t & 1) * kBTile, a_addr, a_sw);
+#pragma unroll 1
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * st + u;
+          if (t >= p.n_taps) break;
+          const int dz = p.tap[t][0], dy = p.tap[t][1], dx = p.tap[t][2];
+          const int shift = dz * (1 << (2 * log2S)) + dy * S + dx;
+          int a_addr[2], a_sw[2];
+          bool any_ok = false;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const bool ok = ((unsigned)(rz[mi] + dz) < (unsigned)S) & ((unsigned)(ry[mi] + dy) < (unsigned)S) &
+                            ((unsigned)(rx[mi] + dx) < (unsigned)S);
+            const int srow = rrow[mi] + shift;
+            a_addr[mi] = ok ? srow * kRowBytes : kZeroOff;   // padding tap -> the zero row
+            a_sw[mi] = ok ? ((srow >> 1) & 7) : 0;
+            any_ok |= ok;
+          }
+          if (__ballot(any_ok) != 0ull)   // a whole-wave padding tap (z-plane halo) issues no MFMAs
+            compute(As, Bs + (grp_cur * 2 + u) * kBTile, a_addr, a_sw);
+        }
         wait_vm0();
         __syncthreads();
       }
@@ -380,7 +400,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 template <int TN, bool KPIPE>
 constexpr size_t lds_bytes() {
   return KPIPE ? (size_t)2 * kABytes + 2 * TN * kRowBytes                 // 160 KiB at TN = 128
-               : (size_t)kABytes + 2 * TN * kRowBytes + kRowBytes;       // + zero row
+               : (size_t)kABytes + 4 * TN * kRowBytes + kRowBytes;       // 4 weight slots + zero row
 }
 
 template <int DT, int TN, bool KPIPE>
