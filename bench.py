@@ -85,10 +85,11 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=100000, help="points per cloud (= queries per rank per step)")
-    ap.add_argument("--batch", type=int, default=4096, help="queries per library call")
+    ap.add_argument("--batch", type=int, default=16384, help="queries per library call")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--uncalibrated-gate", action="store_true", help="raw synthetic gate (routes ~everything to one expert)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,8 +106,17 @@ def main():
 
     cfg = NestiConfig()
     W = weights.synthetic_weights(cfg)
-    est = NormalEstimator(cfg, W, dtype=args.dtype, device=dev, batch=min(args.batch, args.points))
     clouds_np = make_clouds(world, args.points)
+    if not args.uncalibrated_gate:
+        # spread the synthetic gate's arg-max over the experts like a trained gate would (calibrate.py);
+        # every rank derives the same weights from the same 512-query sample of cloud 0
+        from nesti_net_amd.calibrate import calibrate_gate
+        from nesti_net_amd.provider import CloudPatches
+        cp = CloudPatches(clouds_np[0][0], cfg, device=dev)
+        sp, sn = cp.build(0, min(512, args.points))
+        W = calibrate_gate(cfg, W, sp, sn, device=dev)
+        del cp, sp, sn
+    est = NormalEstimator(cfg, W, dtype=args.dtype, device=dev, batch=min(args.batch, args.points))
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
     lib = _lib.load()
 

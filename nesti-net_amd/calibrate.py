@@ -1,0 +1,44 @@
+"""Synthetic-weights helper: make the gating net spread its arg-max over all experts.
+
+With random weights the gate's output is almost input-independent, so every query routes to one
+expert; a trained gate (no checkpoint ships with the reference) does not behave like that.  One probe
+forward over a sample of real MuPS tensors measures the pre-softmax logits of the last gating layer
+(``fc4noise``, ``models/experts_n_est.py:172-177``); its weights are then rescaled per expert so the
+logits have equal spread around a common level and every expert wins about 1/E of the sample.
+Only the synthetic ``fc4noise`` variables change; the graph and every kernel are untouched."""
+import numpy as np
+import torch
+
+from .model import NestiNet
+
+BASE = 5.0      # common logit level, far enough above 0 that fc4's ReLU never clips
+
+
+def calibrate_gate(cfg, W, points, n_eff, device="cuda:0", spread=2.0):
+    """Return a copy of ``W`` whose gate routes the sample ``points``/``n_eff`` (device tensors,
+    [B,S*P,3] / [B,S]) roughly uniformly."""
+    E = cfg.n_experts
+    Wp = dict(W)
+    w4 = np.array(W["fc4noise/weights"], dtype=np.float32, copy=True)       # [128, E]
+    b4 = np.full((E,), BASE, np.float32)
+    w4[:, 0] = 0.0                                                          # expert 0: constant logit BASE
+    w4 *= 0.05 / max(1e-6, float(np.abs(w4).max()))                         # small: no ReLU clipping in the probe
+    Wp["fc4noise/weights"], Wp["fc4noise/biases"] = w4, b4
+    probe = NestiNet(cfg, Wp, dtype="f32", device=device, max_batch=int(points.shape[0]))
+    mups = probe.mups(points, n_eff)
+    probs, _ = probe.gate(mups)
+    torch.cuda.synchronize()
+    del probe
+    p = probs.double().cpu().numpy()
+    d = np.log(p[:, 1:] / p[:, :1])                                         # = w_e.h (bias terms cancel), e >= 1
+    mean, std = d.mean(0), np.maximum(d.std(0), 1e-9)
+    g = spread / std
+    w4n = w4.copy()
+    w4n[:, 1:] = w4[:, 1:] * g[None, :].astype(np.float32)
+    b4n = b4.copy()
+    b4n[1:] = (BASE - mean * g).astype(np.float32)                          # logit_e = BASE + spread * z_e
+    z = BASE + (d - mean) * g                                               # calibrated logits of experts >= 1
+    b4n[0] = np.float32(np.quantile(z.max(1), 1.0 / E))                     # expert 0 wins ~1/E of the sample
+    out = dict(W)
+    out["fc4noise/weights"], out["fc4noise/biases"] = w4n, b4n
+    return out

@@ -354,6 +354,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
       __syncthreads();
       if (log2S == 3 && p.pool_k == 3) pool_lines(std::integral_constant<int, 8>{}, std::integral_constant<int, 3>{}, nh);
       else if (log2S == 2 && p.pool_k == 2) pool_lines(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, nh);
+      else if (log2S == 2 && p.pool_k == 3) pool_lines(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{}, nh);
       else if (log2S == 1 && p.pool_k == 2) pool_lines(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, nh);
       __syncthreads();
     };
@@ -434,8 +435,9 @@ int launch_dt(const ConvParams& p, int TN, hipStream_t stream) {
 int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream) {
   if (p.m_tiles <= 0 || p.n_tiles <= 0) return 0;
   if (p.pool_k > 1 && p.n_taps != 1) NESTI_FAIL("launch_conv: fused pooling needs a 1x1x1 layer");
-  if (p.pool_k > 1 && !((p.log2S == 3 && p.pool_k == 3) || (p.log2S == 2 && p.pool_k == 2) || (p.log2S == 1 && p.pool_k == 2)))
-    NESTI_FAIL("launch_conv: fused pooling supports (S,k) in {(8,3),(4,2),(2,2)}");
+  if (p.pool_k > 1 && !((p.log2S == 3 && p.pool_k == 3) || (p.log2S == 2 && (p.pool_k == 2 || p.pool_k == 3)) ||
+                        (p.log2S == 1 && p.pool_k == 2)))
+    NESTI_FAIL("launch_conv: fused pooling supports (S,k) in {(8,3),(4,3),(4,2),(2,2)}");
   if (dtype == NESTI_BF16) return launch_dt<NESTI_BF16>(p, TN, stream);
   if (dtype == NESTI_F16) return launch_dt<NESTI_F16>(p, TN, stream);
   if (dtype == NESTI_F32) return launch_dt<NESTI_F32>(p, TN, stream);

@@ -103,6 +103,7 @@ struct BufSpec { int log2S; int C; bool f32; };
 struct Op {
   enum Kind { CONV, MAX } kind;
   int in_buf = 0, in_coff = 0, out_buf = 0, out_coff = 0, out_coff2 = 0;
+  int in_cstride = 0;          // 0: the input buffer's channel count; else a flattened view (FC on S^3 x C)
   int layer = -1;
   int C = 0, k = 0, log2S = 0;
   bool out_f32 = false;
@@ -178,7 +179,7 @@ struct Builder {
 
   // fully connected stack on a [NB,1,C] feature (utils/tf_util.py:314-351)
   int fc_stack(Tower& T, int in_buf, ChanMap m, const std::vector<std::string>& scopes, const std::vector<int>& widths,
-               bool last_relu) {
+               bool last_relu, int first_in_cstride = 0) {
     int buf = in_buf;
     for (size_t i = 0; i < scopes.size(); ++i) {
       const bool last = (i + 1 == scopes.size());
@@ -187,6 +188,7 @@ struct Builder {
       const int ob = (int)T.bufs.size() - 1;
       conv(T, scopes[i], 1, 0, buf, 0, m, widths[i], ob, 0, /*bn=*/!last, /*relu=*/last ? last_relu : true, /*fc=*/true,
            /*out_f32=*/last);
+      if (i == 0) T.ops.back().in_cstride = first_in_cstride;
       m.pos.clear(); m.C = Cp;
       for (int c = 0; c < widths[i]; ++c) m.pos.push_back(c);
       buf = ob;
@@ -221,6 +223,28 @@ struct Builder {
     T.n_out = g.cfg.n_experts;
   }
 
+  // ss_norm_est.get_model (models/ss_norm_est.py:35-92): one scale, one tower, no gate.  Dropout
+  // (:76-85) is the identity at inference.  The 2^3 x 1536 feature map is flattened voxel-major
+  // (tf.reshape, :66) into fc1, which here is an FC over a flattened view of the same buffer.
+  void build_single() {
+    Tower& T = g.experts[0];
+    init_tower(T);
+    ChanMap m; m.C = g.mups_cstride;
+    for (int c = 0; c < 20; ++c) m.pos.push_back(c);
+    int b = inception(T, "inception1", 0, m, 128, 3, 5, 3, &m);
+    b = inception(T, "inception2", b, m, 256, 3, 5, 3, &m);
+    b = inception(T, "inception3", b, m, 256, 3, 5, 3, &m);
+    b = maxpool(T, b, m, 3);
+    b = inception(T, "inception5", b, m, 512, 3, 5, 2, &m);
+    b = inception(T, "inception6", b, m, 512, 3, 5, 2, &m);
+    b = maxpool(T, b, m, 2);
+    ChanMap flat; flat.C = 8 * m.C;
+    for (int v = 0; v < 8; ++v)
+      for (size_t c = 0; c < m.pos.size(); ++c) flat.pos.push_back(v * m.C + m.pos[c]);
+    T.out_buf = fc_stack(T, b, flat, {"fc1", "fc2", "fc3", "fc4"}, {1024, 256, 128, 3}, /*last_relu=*/false, flat.C);
+    T.n_out = 3;
+  }
+
   // normal_est_net, 8^3 branch (models/experts_n_est.py:243-291)
   void build_expert(int i) {
     Tower& T = g.experts[i];
@@ -243,7 +267,8 @@ struct Builder {
 };
 
 int build_graph(const nesti_config_t* cfg, Graph* g) {
-  if (cfg->arch != NESTI_ARCH_EXPERTS) NESTI_FAIL("only NESTI_ARCH_EXPERTS is implemented in this build");
+  if (cfg->arch != NESTI_ARCH_EXPERTS && cfg->arch != NESTI_ARCH_SINGLE) NESTI_FAIL("unknown arch");
+  if (cfg->arch == NESTI_ARCH_SINGLE && cfg->n_scales != 1) NESTI_FAIL("NESTI_ARCH_SINGLE (ss_norm_est) takes exactly one scale");
   if (cfg->grid_n != 8) NESTI_FAIL("only the 8^3 Gaussian grid is implemented");
   if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("bad n_scales");
   if (cfg->n_experts < 1 || cfg->n_experts > NESTI_MAX_EXPERTS) NESTI_FAIL("bad n_experts");
@@ -256,6 +281,13 @@ int build_graph(const nesti_config_t* cfg, Graph* g) {
   g->mups_cstride = pad_to(20 * cfg->n_scales, kPad);
   g->layers.clear();
   Builder b(*g);
+  g->gate = Tower();
+  if (cfg->arch == NESTI_ARCH_SINGLE) {
+    g->cfg.n_experts = 1;
+    g->experts.assign(1, Tower());
+    b.build_single();
+    return 0;
+  }
   b.build_gate();
   g->experts.assign(cfg->n_experts, Tower());
   for (int i = 0; i < cfg->n_experts; ++i) b.build_expert(i);
@@ -464,7 +496,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf]; p.wpk = pl.wpk; p.bias = pl.bias;
       p.npoints_ptr = rc.npoints_ptr; p.point_index = ext_in ? rc.point_index : nullptr;
       p.npoints = rc.NB;
-      p.in_cstride = T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
+      p.in_cstride = op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
       p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
       p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S;
       p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
@@ -653,6 +685,7 @@ int nesti_model_mups_cstride(const nesti_model_t* m) { return m ? m->graph.mups_
 int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void* ws_dev, size_t ws_bytes,
                        float* probs_out_dev, int32_t* expert_out_dev, void* stream) {
   if (!m || !mups_dev || !ws_dev) NESTI_FAIL("nesti_gate_forward: null argument");
+  if (m->graph.cfg.arch != NESTI_ARCH_EXPERTS) NESTI_FAIL("nesti_gate_forward: this model has no gating net");
   if (B <= 0) return 0;
   const WsLayout L = ws_layout(m, B);
   if (L.total > ws_bytes) NESTI_FAIL("nesti_gate_forward: workspace too small (see nesti_workspace_bytes)");
@@ -693,6 +726,8 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride, st);
   prof_end(NESTI_PROF_MUPS, st);
   if (rcm) return 1;
+  if (m->graph.cfg.arch == NESTI_ARCH_SINGLE)   // ss_norm_est: the tower's output IS n_pred (test_n_est.py:136-141)
+    return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, nullptr, nullptr, normals_out_dev, st);
   float* probs = probs_out_dev ? probs_out_dev : (float*)(ws + L.probs);
   int32_t* expert = expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert);
   int32_t* counts = (int32_t*)(ws + L.counts);

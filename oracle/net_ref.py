@@ -132,6 +132,24 @@ def expert_forward(mups_slice, W, i, dtype=torch.float64):
     return fc(g, W, "fc4" + s, dtype, bn=False, relu=False)       # :286
 
 
+def single_forward(mups, W, dtype=torch.float64):
+    """``ss_norm_est.get_model`` after the 3DmFV (``models/ss_norm_est.py:49-92``): one scale
+    [B,8,8,8,20] -> normal [B,3].  Dropout (``:76-85``) is the identity at inference."""
+    x = _t(mups, dtype)
+    x = inception(x, W, "inception1", 3, 5, dtype)
+    x = inception(x, W, "inception2", 3, 5, dtype)
+    x = inception(x, W, "inception3", 3, 5, dtype)
+    x = max_pool3d_2(x)
+    x = inception(x, W, "inception5", 3, 5, dtype)
+    x = inception(x, W, "inception6", 3, 5, dtype)
+    x = max_pool3d_2(x)
+    g = x.reshape(x.shape[0], -1)                                  # :66  [B, 2*2*2*1536], voxel-major
+    g = fc(g, W, "fc1", dtype)
+    g = fc(g, W, "fc2", dtype)
+    g = fc(g, W, "fc3", dtype)
+    return fc(g, W, "fc4", dtype, bn=False, relu=False)            # :86
+
+
 def moe_forward(mups, W, expert_dict=None, dtype=torch.float64, top1_only=False):
     """``get_model`` after MuPS (``models/experts_n_est.py:78-108``) plus the
     driver's arg-max / select (``test_n_est_w_experts.py:150-152``).

@@ -158,3 +158,57 @@ def test_ragged_batches_and_padding_rows(setup, net_f32, gpu_device):
     out, ex, pr = net_f32(pad_p, pad_n)
     assert torch.isfinite(out).all() and torch.isfinite(pr).all()
     assert torch.equal(out[:5], full[:5])
+
+
+def test_calibrated_gate_routes_to_many_experts_and_matches_oracle(setup, gpu_device):
+    """Synthetic gate calibrated to spread its arg-max: the fused top-1 forward (gather by expert,
+    per-expert towers with device-side counts, scatter) against the fp64 oracle on 48 queries."""
+    from nesti_net_amd.calibrate import calibrate_gate
+    from nesti_net_amd.model import NestiNet
+    from oracle import mups_ref, net_ref
+    cfg, W, _, _ = setup
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid100k" in p][0])
+    g2 = load_golden_patches([p for p in golden_patch_files() if "ellipsoid20k" in p][0])
+    pts = np.concatenate([g["points"][:24], g2["points"][:24]])
+    n_eff = np.concatenate([g["n_eff"][:24], g2["n_eff"][:24]])
+    p = torch.as_tensor(pts, device=gpu_device)
+    n = torch.as_tensor(n_eff, device=gpu_device)
+    Wc = calibrate_gate(cfg, W, p, n, device=gpu_device)
+    net = NestiNet(cfg, Wc, dtype="f32", device=gpu_device, max_batch=48)
+    normals, expert, probs = net(p, n)
+    torch.cuda.synchronize()
+    ex = expert.cpu().numpy()
+    print("routing histogram:", np.bincount(ex, minlength=7))
+    assert len(np.unique(ex)) >= 5
+    ref = net_ref.moe_forward(mups_ref.mups_assemble(pts, n_eff, 3), Wc, dtype=torch.float64, top1_only=True)
+    srt = np.sort(ref["probs"].numpy(), axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    agree = ex == ref["expert"].numpy()
+    assert np.all(agree | (margin < 1e-4))            # arg-max exact unless the oracle itself is tied to 1e-4
+    assert np.abs(probs.cpu().numpy() - ref["probs"].numpy()).max() < 1e-4
+    c = _cos(normals.cpu().numpy()[agree], ref["normals"].numpy()[agree])
+    assert np.all(1 - c < COS_TOL_F32)
+
+
+def test_single_scale_model_matches_oracle(gpu_device):
+    """BASELINE config 0: ss_norm_est (one radius, one tower, no gate) behind the same boundary."""
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import ARCH_SINGLE, NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from oracle import mups_ref, net_ref
+    g = load_golden_patches([p for p in golden_patch_files() if "sphere8k" in p][0])
+    cfg = NestiConfig(patch_radius=[0.05], n_experts=1, expert_dict={0: [0]}, arch=ARCH_SINGLE)
+    W = weights.synthetic_weights(cfg)
+    assert W["fc1/weights"].shape == (12288, 1024)
+    pts, n_eff = g["points"][:9], g["n_eff"][:9]
+    net = NestiNet(cfg, W, dtype="f32", device=gpu_device, max_batch=9)
+    normals, expert, probs = net(torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff[:, 0], device=gpu_device))
+    torch.cuda.synchronize()
+    assert expert is None and probs is None
+    ref = net_ref.single_forward(mups_ref.mups_assemble(pts, n_eff, 1), W, dtype=torch.float64).numpy()
+    c = _cos(normals.cpu().numpy(), ref)
+    print("ss_norm_est min cosine (f32):", c.min())
+    assert np.all(1 - c < COS_TOL_F32)
+    net16 = NestiNet(cfg, W, dtype="bf16", device=gpu_device, max_batch=9)
+    n16, _, _ = net16(torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device))
+    assert np.all(1 - _cos(n16.cpu().numpy(), ref) < 2e-3)

@@ -1,0 +1,87 @@
+"""File seam and data seam on the GPU: the test_n_est_w_experts.py-compatible CLI, the
+get_data_loader mirror, and batching invariance of the end-to-end estimator."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dataset_dir(tmp_path_factory):
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import synth
+    d = tmp_path_factory.mktemp("pcp")
+    names = ["shapeA", "shapeB"]
+    for i, (nm, shape, n) in enumerate(zip(names, ("ellipsoid", "torus"), (3000, 2500))):
+        pts, nrm = synth.make_cloud(shape, n=n, seed=50 + i, noise=0.00125 * i)
+        np.savetxt(str(d / (nm + ".xyz")), pts, fmt="%.9g")
+        np.savetxt(str(d / (nm + ".normals")), nrm, fmt="%.9g")
+        np.savetxt(str(d / (nm + ".pidx")), np.arange(0, n, 7), fmt="%d")
+    (d / "testset.txt").write_text("\n".join(names) + "\n\n")
+    return str(d) + os.sep
+
+
+def test_data_loader_mirror(dataset_dir, gpu_device):
+    from nesti_net_amd.provider import get_data_loader
+    loader, ds = get_data_loader(dataset_name="testset.txt", batchSize=1000, indir=dataset_dir,
+                                 patch_radius=[0.01, 0.03, 0.05], points_per_patch=512, outputs=[],
+                                 patch_point_count_std=0, seed=3627473, identical_epochs=False, use_pca=False,
+                                 patch_center="point", point_tuple=1, cache_capacity=100, patch_sample_order="full",
+                                 workers=0, dataset_type="test", sparse_patches=False, device=gpu_device)
+    assert ds.shape_names == ["shapeA", "shapeB"] and ds.shape_patch_count == [3000, 2500]
+    assert len(loader) == 6
+    batches = list(loader)
+    assert [b[0].shape[0] for b in batches] == [1000] * 5 + [500]          # a batch may span shapes; last is short
+    assert batches[0][0].shape == (1000, 1536, 3) and batches[0][1].shape == (1000, 3, 3) and batches[0][2].shape == (1000, 3)
+    allp = torch.cat([b[0] for b in batches])
+    alln = torch.cat([b[2] for b in batches])
+    a = ds.get_shape(0).build(0, 3000)
+    b = ds.get_shape(1).build(0, 2500)
+    assert torch.equal(allp, torch.cat([a[0], b[0]])) and torch.equal(alln, torch.cat([a[1], b[1]]))
+    # .npy cache written next to the .xyz like the reference (utils/pcpnet_dataset.py:251)
+    assert os.path.exists(os.path.join(dataset_dir, "shapeA.xyz.npy"))
+    # sparse patches follow <shape>.pidx
+    _, ds2 = get_data_loader(dataset_name="testset.txt", batchSize=64, indir=dataset_dir, patch_radius=[0.01, 0.03, 0.05],
+                             points_per_patch=512, sparse_patches=True, device=gpu_device)
+    assert ds2.shape_patch_count == [len(range(0, 3000, 7)), len(range(0, 2500, 7))]
+    with pytest.raises(ValueError):
+        get_data_loader(dataset_name="testset.txt", batchSize=8, indir=dataset_dir, patch_radius=[0.05],
+                        points_per_patch=512, use_pca=True)
+
+
+def test_cli_writes_reference_file_contract(dataset_dir, tmp_path, gpu_device):
+    from nesti_net_amd import weights
+    from nesti_net_amd.cli import main
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.evaluate import evaluate_set
+    from nesti_net_amd.pipeline import NormalEstimator
+    from nesti_net_amd.provider import load_xyz
+    results = str(tmp_path / "log") + os.sep
+    cfg = NestiConfig()
+    W = weights.synthetic_weights(cfg)
+    os.makedirs(results)
+    weights.save(os.path.join(results, "model.nstw"), W, cfg)
+    rc = main(["--results_path", results, "--dataset_name", "synth", "--dataset_path", dataset_dir,
+               "--testset", "testset.txt", "--sparse_patches", "1", "--batch_size", "128", "--dtype", "bf16"])
+    assert rc == 0
+    out = os.path.join(results, "synth_results")
+    est = NormalEstimator(cfg, W, dtype="bf16", device=gpu_device, batch=300)       # different batching on purpose
+    for nm, n in (("shapeA", 3000), ("shapeB", 2500)):
+        normals = np.loadtxt(os.path.join(out, nm + ".normals"))
+        experts = np.loadtxt(os.path.join(out, nm + ".experts"))
+        probs = np.loadtxt(os.path.join(out, nm + ".experts_probs"))
+        rows = len(range(0, n, 7))
+        assert normals.shape == (rows, 3) and experts.shape == (rows,) and probs.shape == (rows, 7)
+        assert np.allclose(probs.sum(1), 1, atol=1e-5) and np.all(experts == np.argmax(probs, 1))
+        first = open(os.path.join(out, nm + ".normals")).readline().split()[0]
+        assert "e" in first and len(first) >= 22                                    # np.savetxt '%.18e'
+        pts = load_xyz(os.path.join(dataset_dir, nm + ".xyz"))
+        n2, e2, p2 = est.estimate(pts, pidx=np.arange(0, n, 7))
+        assert np.array_equal(e2, experts.astype(np.int32))
+        assert np.array_equal(n2.astype(np.float64), normals)                      # batching-invariant, bit for bit
+    assert os.path.exists(os.path.join(out, "log.txt"))
+    per_shape, avg = evaluate_set(out, dataset_dir, "testset.txt", sparse_patches=True)
+    assert set(per_shape) == {"shapeA", "shapeB"} and 0 <= avg["rms"] <= 90 and 0 <= avg["pgp10"] <= 1
