@@ -186,9 +186,16 @@ def main():
             conv_s = prof_ms[0] / 1e3
             ach = [2.0 * per_pt[j] * rank0_pts / conv_s / 1e12 for j in range(3)]
             peak = PEAK_TFLOPS[args.dtype]
+            # HBM bytes per conv launch from the committed PMC passes (FETCH_SIZE/WRITE_SIZE, separate rocprofv3
+            # runs, gfx950-corrected; scripts/summarize_pmc.py): bytes/query there x queries per launch here
+            traffic = None
+            pmc_file = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pmc_file) and args.dtype == "bf16":
+                per_q = json.load(open(pmc_file))["kernels"]["conv_igemm_kernel"]["hbm_bytes_per_query"]
+                traffic = per_q * rank0_pts / max(1, int(prof_n[0]))
             res["roofline"] = {
                 "bound": "mfma", "kernel": "conv_igemm_kernel (all conv3d/fc layers)", "achieved": ach[1], "peak": peak,
-                "unit": "TFLOP/s", "frac": ach[1] / peak, "traffic": None,
+                "unit": "TFLOP/s", "frac": ach[1] / peak, "traffic": traffic,
                 "algorithmic_gflop_per_point": 2 * per_pt[1] / 1e9, "nominal_tflops": ach[0], "issued_tflops": ach[2],
                 "launches": int(prof_n[0]), "avg_launch_ms": prof_ms[0] / max(1, prof_n[0]),
                 "kernel_ms_per_step": {k: prof_ms[i] / args.steps for i, k in enumerate(_lib.PROF_CATEGORIES)},
