@@ -1,0 +1,231 @@
+"""Reader for the artefacts a trained reference run leaves in ``--results_path``
+(``train_n_est_w_experts.py:120-122, 248-250, 353-354``; consumed at
+``test_n_est_w_experts.py:46-54, 98-105, 201``):
+
+* ``model.ckpt.index`` + ``model.ckpt.data-00000-of-00001`` -- a TensorFlow "tensor bundle": the
+  index is a LevelDB-format table (prefix-compressed keys, restart arrays, 48-byte footer) whose
+  values are ``BundleEntryProto`` messages (dtype, shape, shard_id, offset, size, crc32c) pointing
+  into the data shard;
+* ``parameters.p`` -- the pickled argparse Namespace of the training run (Python 2);
+* ``gmm.p`` -- the pickled sklearn GaussianMixture of the Gaussian grid (Python 2).
+
+No TensorFlow, sklearn or Python 2 is needed.  TensorFlow itself is not installable here and the
+reference ships no checkpoint, so this reader is pinned only against bundles written by the
+format-level writer in ``tests/test_tf_ckpt.py`` (parity unpinned against a real TF-written file).
+"""
+import io
+import json
+import os
+import pickle
+import struct
+
+import numpy as np
+
+from .config import NestiConfig
+
+TABLE_MAGIC = 0xdb4775248b80fb57
+_DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64, 19: np.float16}   # tensorflow/core/framework/types.proto
+
+
+# ---- protobuf / varint helpers -----------------------------------------------------------------
+def _varint(buf, pos):
+    res, shift = 0, 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        res |= (b & 0x7f) << shift
+        if not b & 0x80:
+            return res, pos
+        shift += 7
+
+
+def _fields(buf):
+    """Yield (field_number, wire_type, value) of one protobuf message."""
+    pos = 0
+    while pos < len(buf):
+        key, pos = _varint(buf, pos)
+        fn, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 1:
+            v = buf[pos:pos + 8]
+            pos += 8
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            v = buf[pos:pos + ln]
+            pos += ln
+        elif wt == 5:
+            v = buf[pos:pos + 4]
+            pos += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield fn, wt, v
+
+
+def _parse_entry(buf):
+    """BundleEntryProto (tensorflow/core/protobuf/tensor_bundle.proto)."""
+    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0}
+    for fn, wt, v in _fields(buf):
+        if fn == 1:
+            e["dtype"] = v
+        elif fn == 2:                                  # TensorShapeProto: repeated Dim dim = 2 { int64 size = 1 }
+            for f2, _, v2 in _fields(v):
+                if f2 == 2:
+                    size = 0
+                    for f3, _, v3 in _fields(v2):
+                        if f3 == 1:
+                            size = v3
+                    e["shape"].append(size)
+        elif fn == 3:
+            e["shard_id"] = v
+        elif fn == 4:
+            e["offset"] = v
+        elif fn == 5:
+            e["size"] = v
+    return e
+
+
+# ---- LevelDB table ---------------------------------------------------------------------------
+def _read_block(data, offset, size):
+    raw = data[offset:offset + size]
+    ctype = data[offset + size]                        # 1-byte compression type + 4-byte crc follow the block
+    if ctype != 0:
+        raise ValueError("compressed table blocks (type %d) are not supported" % ctype)
+    n_restarts = struct.unpack("<I", raw[-4:])[0]
+    end = len(raw) - 4 - 4 * n_restarts
+    pos, key = 0, b""
+    out = []
+    while pos < end:
+        shared, pos = _varint(raw, pos)
+        non_shared, pos = _varint(raw, pos)
+        vlen, pos = _varint(raw, pos)
+        key = key[:shared] + raw[pos:pos + non_shared]
+        pos += non_shared
+        out.append((key, raw[pos:pos + vlen]))
+        pos += vlen
+    return out
+
+
+def read_index(index_path):
+    """-> {variable name: BundleEntryProto dict} (the header entry with the empty key is dropped)."""
+    data = open(index_path, "rb").read()
+    if len(data) < 48 or struct.unpack("<Q", data[-8:])[0] != TABLE_MAGIC:
+        raise ValueError("%s is not a TensorFlow tensor-bundle index" % index_path)
+    footer = data[-48:]
+    _, p = _varint(footer, 0)                          # metaindex handle (unused)
+    _, p = _varint(footer, p)
+    idx_off, p = _varint(footer, p)
+    idx_size, p = _varint(footer, p)
+    entries = {}
+    for _, handle in _read_block(data, idx_off, idx_size):
+        off, q = _varint(handle, 0)
+        size, q = _varint(handle, q)
+        for key, val in _read_block(data, off, size):
+            if key:
+                entries[key.decode()] = _parse_entry(val)
+    return entries
+
+
+def read_bundle(prefix):
+    """``saver.restore`` without TF: prefix e.g. ``.../model.ckpt`` -> {name: ndarray}."""
+    entries = read_index(prefix + ".index")
+    shards = {}
+    out = {}
+    for name, e in entries.items():
+        if e["dtype"] not in _DTYPES:
+            continue                                   # e.g. string tensors of the saver itself
+        sid = e["shard_id"]
+        if sid not in shards:
+            n = max(x["shard_id"] for x in entries.values()) + 1
+            shards[sid] = np.memmap("%s.data-%05d-of-%05d" % (prefix, sid, n), dtype=np.uint8, mode="r")
+        raw = np.asarray(shards[sid][e["offset"]:e["offset"] + e["size"]])
+        out[name] = raw.view(_DTYPES[e["dtype"]]).reshape(e["shape"]).copy()
+    return out
+
+
+# ---- variable name mapping ----------------------------------------------------------------------
+def map_variables(raw, expected):
+    """TF variable names -> this package's names (``weights.describe``).
+
+    ``<scope>/weights|biases`` and ``<scope>/bn/beta|gamma`` are used verbatim
+    (``utils/tf_util.py:292,301,473-476``).  The EMA shadows of the batch statistics are named by
+    ``tf.train.ExponentialMovingAverage`` after the ``moments`` ops (``utils/tf_util.py:477-479``),
+    so they are discovered: under ``<scope>/bn/`` the two keys ending in
+    ``ExponentialMovingAverage``; the variance is the one whose op name has the ``_1`` / 'variance'
+    suffix."""
+    out = {}
+    for name, shape in expected.items():
+        if name in raw:
+            arr = raw[name]
+        elif name.endswith("/bn/mean") or name.endswith("/bn/var"):
+            scope = name[:name.rindex("/")] + "/"
+            cands = sorted(k for k in raw if k.startswith(scope) and k.endswith("ExponentialMovingAverage"))
+            if len(cands) != 2:
+                raise KeyError("expected 2 EMA shadow variables under %s, found %s" % (scope, cands))
+            is_var = [("Squeeze_1" in k) or ("variance" in k) for k in cands]
+            if sum(is_var) != 1:
+                raise KeyError("cannot tell mean from variance among %s" % cands)
+            arr = raw[cands[is_var.index(name.endswith("/bn/var"))]]
+        else:
+            raise KeyError("variable %s not found in the checkpoint" % name)
+        if tuple(arr.shape) != tuple(shape):
+            raise ValueError("%s: checkpoint shape %s != graph shape %s" % (name, tuple(arr.shape), tuple(shape)))
+        out[name] = np.ascontiguousarray(arr, dtype=np.float32)
+    return out
+
+
+# ---- parameters.p / gmm.p -------------------------------------------------------------------------
+class _Stub:
+    """Stand-in for classes that do not exist here (sklearn.mixture.gaussian_mixture.GaussianMixture)."""
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+
+class _Unpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module.startswith("sklearn"):
+            return _Stub
+        if module == "copy_reg":
+            module = "copyreg"
+        if module == "__builtin__":
+            module = "builtins"
+        return super().find_class(module, name)
+
+
+def _load_py2_pickle(path):
+    with open(path, "rb") as f:
+        return _Unpickler(io.BytesIO(f.read()), encoding="latin1").load()
+
+
+def load_parameters(path):
+    """``parameters.p`` -> NestiConfig (``test_n_est_w_experts.py:46-54``)."""
+    ns = _load_py2_pickle(path)
+    ed = json.loads(ns.expert_dict)                                      # JSON-in-JSON, :53-54
+    ed = {int(k): (json.loads(v) if isinstance(v, str) else v) for k, v in ed.items()}
+    variance = getattr(ns, "gmm_variance", 0.0156)
+    n_gauss = getattr(ns, "n_gaussians", 8)
+    return NestiConfig(patch_radius=[float(r) for r in ns.patch_radius], num_point=int(ns.num_point),
+                       n_gaussians=int(n_gauss), gmm_variance=float(variance), n_experts=int(ns.n_experts),
+                       expert_dict=ed)
+
+
+def load_gmm(path):
+    """``gmm.p`` -> (weights_, means_, covariances_) as float64 arrays."""
+    g = _load_py2_pickle(path)
+    return np.asarray(g.weights_), np.asarray(g.means_), np.asarray(g.covariances_)
+
+
+def load_reference_model(results_path):
+    """Everything ``test_n_est_w_experts.py`` reads from a trained-model directory ->
+    (NestiConfig, weights dict) ready for :class:`NestiNet` / ``weights.save``."""
+    from . import weights as wts
+    cfg = load_parameters(os.path.join(results_path, "parameters.p"))
+    gp = os.path.join(results_path, "gmm.p")
+    if os.path.exists(gp):
+        w, mu, cov = load_gmm(gp)
+        n = int(round(len(w) ** (1.0 / 3.0)))
+        if n != cfg.n_gaussians or abs(float(cov.flat[0]) - cfg.gmm_variance) > 1e-12:
+            cfg.n_gaussians, cfg.gmm_variance = n, float(cov.flat[0])
+    raw = read_bundle(os.path.join(results_path, "model.ckpt"))
+    return cfg, map_variables(raw, wts.describe(cfg))
