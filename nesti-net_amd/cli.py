@@ -3,9 +3,10 @@
 ``<shape>.pidx``) and same outputs (``<results_path>/<dataset_name>_results/<shape>.normals``,
 ``.experts``, ``.experts_probs`` written with ``np.savetxt`` like ``:182-188``, plus ``log.txt``).
 
-The trained-model directory holds ``model.nstw`` (variables + hyper-parameters, see
-:mod:`.weights`) instead of ``parameters.p`` / ``gmm.p`` / ``model.ckpt``; ``--synthetic_weights``
-substitutes seeded random weights (no checkpoint ships with the reference)."""
+The trained-model directory holds either ``model.nstw`` (variables + hyper-parameters, see
+:mod:`.weights`) or the reference's own ``parameters.p`` / ``gmm.p`` / ``model.ckpt.*`` (read by
+:mod:`.tf_ckpt` without TensorFlow); ``--synthetic_weights`` substitutes seeded random weights (no
+checkpoint ships with the reference)."""
 import argparse
 import os
 import sys
@@ -57,6 +58,11 @@ def main(argv=None):
         printout("Loading model %s" % model_file)
         W, cfg = wts.load(model_file)
         cfg = cfg or NestiConfig()
+    elif os.path.exists(os.path.join(results_path, "model.ckpt.index")) and os.path.exists(os.path.join(results_path, "parameters.p")):
+        # the reference's own artefacts: parameters.p / gmm.p / model.ckpt (test_n_est_w_experts.py:46-54, 98-105, 201)
+        from . import tf_ckpt
+        printout("Loading model %s" % os.path.join(results_path, "model.ckpt"))
+        cfg, W = tf_ckpt.load_reference_model(results_path)
     elif FLAGS.synthetic_weights:
         cfg = NestiConfig()
         printout("No %s: using synthetic weights (seed %d)" % (model_file, wts.WEIGHT_SEED))
