@@ -100,7 +100,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_pg = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -129,7 +130,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -146,7 +147,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_pg:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -203,7 +204,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, W, clouds_np[0][0])
         print(json.dumps(res))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -38,7 +38,7 @@ def unpack_results(buf):
 def gather_shards(normals, expert, probs, n_rows, group=None):
     """All-gather the per-rank shard results of one shape into full-length tensors on every rank."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return normals, expert, probs
     ms = max_shard(n_rows, world)
     mine = pack_results(normals, expert, probs, ms)
