@@ -34,13 +34,18 @@ from nesti_net_amd.pipeline import NormalEstimator  # noqa: E402
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
 
 
-def make_clouds(n_clouds, n_points):
+def make_clouds(n_clouds, n_points, stream=False):
     """Cloud i: shape and PCPNet noise level cycle with i (BASELINE config 3); cloud 0 is the
-    no-noise ellipsoid the survey measured."""
+    no-noise ellipsoid the survey measured.  ``stream`` (BASELINE config 4): sizes vary between
+    n_points/2 and n_points and the varying-density sets (gradient / striped) are mixed in."""
     shapes = ("ellipsoid", "sphere", "torus", "box")
     out = []
     for i in range(n_clouds):
-        pts, nrm = synth.make_cloud(shapes[i % 4], n=n_points, seed=1234 + i, noise=synth.PCPNET_NOISE[i % 4])
+        n, dens = n_points, None
+        if stream:
+            n = n_points // 2 + (i * 7919) % (n_points // 2 + 1)
+            dens = (None, "gradient", "striped")[i % 3]
+        pts, nrm = synth.make_cloud(shapes[i % 4], n=n, seed=1234 + i, noise=synth.PCPNET_NOISE[i % 4], density=dens)
         out.append((pts, nrm))
     return out
 
@@ -89,6 +94,10 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--stream-clouds", type=int, default=0,
+                    help="BASELINE config 4: this many clouds of varying size/density in flight per step instead of one "
+                         "--points cloud per rank (not the headline workload)")
+    ap.add_argument("--graph", action="store_true", help="replay the forward of full batches from a captured hipGraph")
     ap.add_argument("--uncalibrated-gate", action="store_true", help="raw synthetic gate (routes ~everything to one expert)")
     args = ap.parse_args()
 
@@ -107,7 +116,7 @@ def main():
 
     cfg = NestiConfig()
     W = weights.synthetic_weights(cfg)
-    clouds_np = make_clouds(world, args.points)
+    clouds_np = make_clouds(args.stream_clouds, args.points, stream=True) if args.stream_clouds else make_clouds(world, args.points)
     if not args.uncalibrated_gate:
         # spread the synthetic gate's arg-max over the experts like a trained gate would (calibrate.py);
         # every rank derives the same weights from the same 512-query sample of cloud 0
@@ -117,7 +126,7 @@ def main():
         sp, sn = cp.build(0, min(512, args.points))
         W = calibrate_gate(cfg, W, sp, sn, device=dev)
         del cp, sp, sn
-    est = NormalEstimator(cfg, W, dtype=args.dtype, device=dev, batch=min(args.batch, args.points))
+    est = NormalEstimator(cfg, W, dtype=args.dtype, device=dev, batch=min(args.batch, args.points), use_graph=args.graph)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
     lib = _lib.load()
 
@@ -158,7 +167,7 @@ def main():
         lib.nesti_profile_enable(0)
 
     if rank == 0:
-        total_normals = world * args.points * args.steps
+        total_normals = sum(len(p) for p, _ in clouds_np) * args.steps
         normals, expert, probs = [t.cpu().numpy() for t in out]
         hist = np.bincount(expert, minlength=cfg.n_experts)
         res = {
@@ -167,8 +176,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "full MoE hot path (ball query + MuPS 3 scales 8^3 + gate + top-1 of 7 experts), "
-                                   "%d cloud(s) x %d points, rows sharded over %d rank(s) + all-gather"
-                                   % (world, args.points, world),
+                                   "%d cloud(s) x %s points, rows sharded over %d rank(s) + all-gather"
+                                   % (len(clouds_np), ("%d..%d" % (min(len(p) for p, _ in clouds_np), max(len(p) for p, _ in clouds_np)))
+                                      if args.stream_clouds else str(args.points), world),
                        "points_per_cloud": args.points, "batch": est.batch, "weights": "synthetic seed %d" % weights.WEIGHT_SEED,
                        "routing_histogram": hist.tolist(), "parallelism": "dp%d (query rows)" % world},
             "rms_angle_deg_vs_analytic": rms_angle_deg(normals, clouds_np[-1][1]),
@@ -183,7 +193,7 @@ def main():
             # rank 0's queries per step: its shard of every cloud; routing of the last cloud stands in for all
             frac = hist / max(1, hist.sum())
             per_pt = [macs[-1][j] + sum(frac[e] * macs[e][j] for e in range(cfg.n_experts)) for j in range(3)]
-            rank0_pts = args.points * args.steps
+            rank0_pts = sum(ndist.shard_range(len(p), 0, world)[1] for p, _ in clouds_np) * args.steps
             conv_s = prof_ms[0] / 1e3
             ach = [2.0 * per_pt[j] * rank0_pts / conv_s / 1e12 for j in range(3)]
             peak = PEAK_TFLOPS[args.dtype]

@@ -11,12 +11,37 @@ from .provider import CloudPatches
 
 
 class NormalEstimator:
-    def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", batch=4096, seed=3627473):
+    """``use_graph=True`` captures the forward pass of a full batch (MuPS + gate + routing + experts,
+    ~250 launches whose sizes depend only on the batch size -- expert counts are read on the device) into a
+    hipGraph once and replays it; only worthwhile for small batches where launch gaps matter."""
+
+    def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", batch=4096, seed=3627473,
+                 use_graph=False):
         self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
         self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=self.batch)
-        S, P = cfg.n_scales, cfg.num_point
+        S, P, E = cfg.n_scales, cfg.num_point, cfg.n_experts
         self._points = torch.empty((self.batch, S * P, 3), dtype=torch.float32, device=self.device)
         self._n_eff = torch.empty((self.batch, S), dtype=torch.int32, device=self.device)
+        self.use_graph, self._graph = bool(use_graph), None
+        if self.use_graph:
+            self._g_out = (torch.empty((self.batch, 3), dtype=torch.float32, device=self.device),
+                           torch.empty((self.batch,), dtype=torch.int32, device=self.device),
+                           torch.empty((self.batch, E), dtype=torch.float32, device=self.device))
+
+    def _capture(self):
+        """Warm up (sets kernel attributes, fills the workspace pointers) then capture one forward."""
+        self._points.zero_()
+        self._n_eff.fill_(1)
+        with torch.cuda.device(self.device):
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.net.forward(self._points, self._n_eff, out=self._g_out)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self.net.forward(self._points, self._n_eff, out=self._g_out)
 
     def prepare(self, pts, pidx=None):
         """Upload a cloud and build its search grid (replaces ``load_shape``)."""
@@ -41,7 +66,16 @@ class NormalEstimator:
             p, n = self._points[:take], self._n_eff[:take]
             cloud.build(first + done, take, out=(p, n))
             sl = slice(done, done + take)
-            self.net.forward(p, n, out=(normals[sl], expert[sl], probs[sl]))
+            if self.use_graph and take == self.batch:
+                if self._graph is None:
+                    self._capture()
+                    cloud.build(first + done, take, out=(p, n))     # capture ran on placeholder inputs
+                self._graph.replay()
+                normals[sl].copy_(self._g_out[0])
+                expert[sl].copy_(self._g_out[1])
+                probs[sl].copy_(self._g_out[2])
+            else:
+                self.net.forward(p, n, out=(normals[sl], expert[sl], probs[sl]))
             done += take
         return normals, expert, probs
 
