@@ -90,13 +90,14 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=100000, help="points per cloud (= queries per rank per step)")
-    ap.add_argument("--batch", type=int, default=16384, help="queries per library call")
+    ap.add_argument("--batch", type=int, default=8192, help="queries per library call")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--stream-clouds", type=int, default=0,
                     help="BASELINE config 4: this many clouds of varying size/density in flight per step instead of one "
                          "--points cloud per rank (not the headline workload)")
+    ap.add_argument("--streams", type=int, default=2, help="alternate consecutive batches between this many HIP streams")
     ap.add_argument("--graph", action="store_true", help="replay the forward of full batches from a captured hipGraph")
     ap.add_argument("--uncalibrated-gate", action="store_true", help="raw synthetic gate (routes ~everything to one expert)")
     args = ap.parse_args()
@@ -126,7 +127,8 @@ def main():
         sp, sn = cp.build(0, min(512, args.points))
         W = calibrate_gate(cfg, W, sp, sn, device=dev)
         del cp, sp, sn
-    est = NormalEstimator(cfg, W, dtype=args.dtype, device=dev, batch=min(args.batch, args.points), use_graph=args.graph)
+    est = NormalEstimator(cfg, W, dtype=args.dtype, device=dev, batch=min(args.batch, args.points), use_graph=args.graph,
+                          n_streams=args.streams)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
     lib = _lib.load()
 

@@ -70,7 +70,7 @@ def main(argv=None):
     else:
         raise SystemExit("%s not found (pass --synthetic_weights to run without a trained model)" % model_file)
     device = "cuda:%d" % FLAGS.gpu
-    est = NormalEstimator(cfg, W, dtype=FLAGS.dtype, device=device, batch=max(FLAGS.batch_size, 4096))
+    est = NormalEstimator(cfg, W, dtype=FLAGS.dtype, device=device, batch=max(FLAGS.batch_size, 4096), n_streams=2)
     printout("Model restored.")
 
     dataset = PointcloudPatchDataset(pc_path, FLAGS.testset, cfg, seed=3627473, sparse_patches=FLAGS.sparse_patches,

@@ -105,6 +105,11 @@ class NestiNet:
             self._ws_batch = int(batch)
         return self._ws
 
+    def new_workspace(self, batch):
+        """An additional scratch arena (one per concurrently running stream)."""
+        nbytes = self.lib.nesti_workspace_bytes(self._handle, int(batch))
+        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+
     # -- pieces (tests and the reference-shaped API) ---------------------------------------
     def mups(self, points, n_eff, stream=None):
         """MuPS in the model's internal layout [B, R^3... , cstride] / dtype."""
@@ -139,13 +144,13 @@ class NestiNet:
         return out
 
     # -- the sess.run equivalent -----------------------------------------------------------
-    def forward(self, points, n_eff, out=None, stream=None):
+    def forward(self, points, n_eff, out=None, stream=None, ws=None):
         """points [B,S*P,3] f32 cuda, n_eff [B,S] -> (normals [B,3] f32, expert [B] int32, probs [B,E] f32).
 
         Equals ``n_est[argmax(experts_prob), range(B)]``, ``argmax`` and
         ``transpose(experts_prob)`` of ``test_n_est_w_experts.py:148-152``."""
         B = points.shape[0]
-        ws = self.reserve(B)
+        ws = self.reserve(B) if ws is None else ws
         E = self.cfg.n_experts
         points = points.contiguous()
         if points.dtype != torch.float32:

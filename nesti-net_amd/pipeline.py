@@ -16,12 +16,19 @@ class NormalEstimator:
     hipGraph once and replays it; only worthwhile for small batches where launch gaps matter."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", batch=4096, seed=3627473,
-                 use_graph=False):
+                 use_graph=False, n_streams=1):
         self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
         self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=self.batch)
         S, P, E = cfg.n_scales, cfg.num_point, cfg.n_experts
         self._points = torch.empty((self.batch, S * P, 3), dtype=torch.float32, device=self.device)
         self._n_eff = torch.empty((self.batch, S), dtype=torch.int32, device=self.device)
+        # n_streams > 1: consecutive batches alternate between HIP streams (own staging buffers and scratch
+        # arena each), so one batch's partially filled last workgroup rounds overlap the other's kernels
+        self.n_streams = 1 if use_graph else max(1, int(n_streams))
+        self._lanes = []
+        for i in range(1, self.n_streams):
+            self._lanes.append((torch.cuda.Stream(device=self.device), torch.empty_like(self._points),
+                                torch.empty_like(self._n_eff), self.net.new_workspace(self.batch)))
         self.use_graph, self._graph = bool(use_graph), None
         if self.use_graph:
             self._g_out = (torch.empty((self.batch, 3), dtype=torch.float32, device=self.device),
@@ -60,12 +67,26 @@ class NormalEstimator:
             probs = torch.empty((count, E), dtype=torch.float32, device=self.device)
         else:
             normals, expert, probs = out
-        done = 0
+        done, it = 0, 0
+        main = torch.cuda.current_stream(self.device)
+        if self.n_streams > 1:
+            for lane in self._lanes:
+                lane[0].wait_stream(main)             # the cloud's grid (and earlier work) is ready
         while done < count:
             take = min(self.batch, count - done)
+            sl = slice(done, done + take)
+            lane = it % self.n_streams
+            it += 1
+            if lane > 0:
+                st, pb, nb, ws = self._lanes[lane - 1]
+                p, n = pb[:take], nb[:take]
+                with torch.cuda.stream(st):
+                    cloud.build(first + done, take, out=(p, n), stream=st)
+                    self.net.forward(p, n, out=(normals[sl], expert[sl], probs[sl]), stream=st, ws=ws)
+                done += take
+                continue
             p, n = self._points[:take], self._n_eff[:take]
             cloud.build(first + done, take, out=(p, n))
-            sl = slice(done, done + take)
             if self.use_graph and take == self.batch:
                 if self._graph is None:
                     self._capture()
@@ -77,6 +98,8 @@ class NormalEstimator:
             else:
                 self.net.forward(p, n, out=(normals[sl], expert[sl], probs[sl]))
             done += take
+        for lane in self._lanes:
+            main.wait_stream(lane[0])                 # results are ordered on the caller's stream again
         return normals, expert, probs
 
     def estimate(self, pts, pidx=None):

@@ -107,3 +107,18 @@ def test_hipgraph_replay_matches_eager(gpu_device):
         n_e, e_e, p_e = eager.estimate(c, pidx=np.arange(0, len(c), 9))
         assert np.array_equal(n_g.cpu().numpy(), n_e) and np.array_equal(e_g.cpu().numpy(), e_e)
         assert np.array_equal(p_g.cpu().numpy(), p_e)
+
+
+def test_two_stream_batches_match_single_stream(gpu_device):
+    from nesti_net_amd import synth, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.pipeline import NormalEstimator
+    cfg = NestiConfig()
+    W = weights.synthetic_weights(cfg)
+    one = NormalEstimator(cfg, W, dtype="bf16", device=gpu_device, batch=300)
+    two = NormalEstimator(cfg, W, dtype="bf16", device=gpu_device, batch=300, n_streams=2)
+    pts = synth.make_cloud("ellipsoid", n=5000, seed=3)[0]
+    a = one.estimate(pts, pidx=np.arange(0, 5000, 4))
+    b = two.estimate(pts, pidx=np.arange(0, 5000, 4))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
