@@ -61,7 +61,7 @@ def cpu_baseline(cfg, W, pts):
     """The oracle (numpy/scipy/torch-CPU restatement of the reference) timed on this host on a
     bounded sample of the same workload; per-stage seconds per query are summed."""
     from oracle import mups_ref, net_ref, patches_ref
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)      # torch-CPU conv3d stops scaling (and regresses) well before 256 threads
     torch.set_num_threads(cores)
     n_patch, n_mups, n_net = 2048, 32, 128
     tree = patches_ref.build_tree(pts)
@@ -90,14 +90,16 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=100000, help="points per cloud (= queries per rank per step)")
-    ap.add_argument("--batch", type=int, default=8192, help="queries per library call")
+    ap.add_argument("--batch", type=int, default=25000, help="queries per library call")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--stream-clouds", type=int, default=0,
                     help="BASELINE config 4: this many clouds of varying size/density in flight per step instead of one "
                          "--points cloud per rank (not the headline workload)")
-    ap.add_argument("--streams", type=int, default=2, help="alternate consecutive batches between this many HIP streams")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="alternate consecutive batches between this many HIP streams (2 is ~3% faster, but kernels of the two "
+                         "streams overlap, so per-launch durations no longer describe one kernel)")
     ap.add_argument("--graph", action="store_true", help="replay the forward of full batches from a captured hipGraph")
     ap.add_argument("--uncalibrated-gate", action="store_true", help="raw synthetic gate (routes ~everything to one expert)")
     args = ap.parse_args()
