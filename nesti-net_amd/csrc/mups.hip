@@ -24,36 +24,55 @@ constexpr int kG = kR * kR * kR;
 constexpr int kChunk = 64;     // patch points staged per sweep
 constexpr int kThreads = 256;
 
+typedef float f2 __attribute__((ext_vector_type(2)));   // the thread's two Gaussians: packed-f32 VALU (v_pk_*)
+
 struct Stats {
-  float sq, mq;                 // sum Q, max Q
-  float mu_max[3], mu_min[3], mu_sum[3];
-  float sg_max[3], sg_min[3], sg_sum[3];
+  f2 sq, mq;                    // sum Q, max Q
+  f2 mu_max[3], mu_min[3], mu_sum[3];
+  f2 sg_max[3], sg_min[3], sg_sum[3];
   __device__ __forceinline__ void init() {
-    sq = 0.f;
-    mq = -INFINITY;
+    sq = f2{0.f, 0.f};
+    mq = f2{-INFINITY, -INFINITY};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      mu_max[c] = -INFINITY; mu_min[c] = INFINITY; mu_sum[c] = 0.f;
-      sg_max[c] = -INFINITY; sg_min[c] = INFINITY; sg_sum[c] = 0.f;
+      mu_max[c] = f2{-INFINITY, -INFINITY}; mu_min[c] = f2{INFINITY, INFINITY}; mu_sum[c] = f2{0.f, 0.f};
+      sg_max[c] = f2{-INFINITY, -INFINITY}; sg_min[c] = f2{INFINITY, INFINITY}; sg_sum[c] = f2{0.f, 0.f};
     }
   }
   // Q = posterior; d[c] = (x_c - mu_c)/sigma; e[c] = d[c]^2 - 1
-  __device__ __forceinline__ void update(float Q, const float (&d)[3], const float (&e)[3]) {
+  __device__ __forceinline__ void update(f2 Q, const f2 (&d)[3], const f2 (&e)[3]) {
     sq += Q;
-    mq = fmaxf(mq, Q);
+    mq = __builtin_elementwise_max(mq, Q);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const float m = Q * d[c];                      // utils/tf_util.py:713
-      mu_max[c] = fmaxf(mu_max[c], m);
-      mu_min[c] = fminf(mu_min[c], m);
+      const f2 m = Q * d[c];                         // utils/tf_util.py:713
+      mu_max[c] = __builtin_elementwise_max(mu_max[c], m);
+      mu_min[c] = __builtin_elementwise_min(mu_min[c], m);
       mu_sum[c] += m;
-      const float v = Q * e[c];                      // utils/tf_util.py:717
-      sg_max[c] = fmaxf(sg_max[c], v);
-      sg_min[c] = fminf(sg_min[c], v);
+      const f2 v = Q * e[c];                         // utils/tf_util.py:717
+      sg_max[c] = __builtin_elementwise_max(sg_max[c], v);
+      sg_min[c] = __builtin_elementwise_min(sg_min[c], v);
       sg_sum[c] += v;
     }
   }
 };
+
+// raw statistics of ONE of the two Gaussians
+struct Stats1 {
+  float sq, mq;
+  float mu_max[3], mu_min[3], mu_sum[3];
+  float sg_max[3], sg_min[3], sg_sum[3];
+};
+__device__ __forceinline__ Stats1 pick(const Stats& s, int which) {
+  Stats1 o;
+  o.sq = s.sq[which]; o.mq = s.mq[which];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o.mu_max[c] = s.mu_max[c][which]; o.mu_min[c] = s.mu_min[c][which]; o.mu_sum[c] = s.mu_sum[c][which];
+    o.sg_max[c] = s.sg_max[c][which]; o.sg_min[c] = s.sg_min[c][which]; o.sg_sum[c] = s.sg_sum[c][which];
+  }
+  return o;
+}
 
 __device__ __forceinline__ float signed_sqrt(float v) {   // utils/tf_util.py:732-735, alpha = 0.5
   return copysignf(sqrtf(fabsf(v)), v);
@@ -79,7 +98,7 @@ __device__ __forceinline__ void store20(void* out, size_t elem_off, const float 
 
 // Turn raw statistics into the 20 channels of one Gaussian, before L2 normalisation.
 // Channel order: utils/tf_util.py:710-719,744-747.
-__device__ __forceinline__ void finish(const Stats& s, int nrows, bool has_masked, float m_f,
+__device__ __forceinline__ void finish(const Stats1& s, int nrows, bool has_masked, float m_f,
                                        float w, float (&v)[20]) {
   const float rsw = 1.0f / sqrtf(w);           // 1/sqrt(w)        :709,714
   const float rs2w = 1.0f / sqrtf(2.0f * w);   // 1/sqrt(2w)       :718
@@ -108,7 +127,10 @@ __global__ __launch_bounds__(kThreads) void mups_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ n_eff, int B,
                                                         int S, int P, void* __restrict__ out,
                                                         int cstride, float sigma, float w) {
-  __shared__ float4 stage[kChunk][3 * kR];   // (q, d, d^2-1, -) per point, axis, grid index
+  // per staged point: x axis as 4 pairs (i, i+4) laid out for packed math: {q_i, q_i+4, d_i, d_i+4} and
+  // {e_i, e_i+4, -, -}; y and z axes as {q, d, d^2-1, -} per grid index
+  __shared__ float4 stage_x[kChunk][2 * (kR / 2)];
+  __shared__ float4 stage_yz[kChunk][2 * kR];
   __shared__ float red[kThreads / 64][20];
   __shared__ float norm2[20];
 
@@ -137,9 +159,8 @@ __global__ __launch_bounds__(kThreads) void mups_kernel(const float* __restrict_
     const bool has_masked = nrows < P;
     const float* pts = points + ((size_t)b * S + s) * (size_t)P * 3;
 
-    Stats a0, a1;
-    a0.init();
-    a1.init();
+    Stats acc;
+    acc.init();
 
     for (int c0 = 0; c0 < nrows; c0 += kChunk) {
       __syncthreads();
@@ -155,36 +176,39 @@ __global__ __launch_bounds__(kThreads) void mups_kernel(const float* __restrict_
             e[i] = expf(-0.5f * d[i] * d[i]);
             sum += e[i];
           }
+          if (axis == 0) {
 #pragma unroll
-          for (int i = 0; i < kR; ++i)
-            stage[nl][axis * kR + i] = make_float4(e[i] / sum, d[i], d[i] * d[i] - 1.0f, 0.f);
+            for (int i = 0; i < kR / 2; ++i) {
+              stage_x[nl][2 * i] = make_float4(e[i] / sum, e[i + 4] / sum, d[i], d[i + 4]);
+              stage_x[nl][2 * i + 1] = make_float4(d[i] * d[i] - 1.0f, d[i + 4] * d[i + 4] - 1.0f, 0.f, 0.f);
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < kR; ++i)
+              stage_yz[nl][(axis - 1) * kR + i] = make_float4(e[i] / sum, d[i], d[i] * d[i] - 1.0f, 0.f);
+          }
         }
       }
       __syncthreads();
       const int cnt = min(kChunk, nrows - c0);
       for (int nl = 0; nl < cnt; ++nl) {
-        const float4 X0 = stage[nl][i0];
-        const float4 X1 = stage[nl][i0 + 4];
-        const float4 Y = stage[nl][kR + j];
-        const float4 Z = stage[nl][2 * kR + k];
+        const float4 XA = stage_x[nl][2 * i0];
+        const float4 XB = stage_x[nl][2 * i0 + 1];
+        const float4 Y = stage_yz[nl][j];
+        const float4 Z = stage_yz[nl][kR + k];
+        asm volatile("" ::"v"(Y.w), "v"(Z.w));   // keep these ds_read_b128: a 12-byte ds_read_b96 costs 8 LDS cycles, not 4
         const float qyz = Y.x * Z.x;
-        {
-          const float d[3] = {X0.y, Y.y, Z.y};
-          const float e[3] = {X0.z, Y.z, Z.z};
-          a0.update(X0.x * qyz, d, e);
-        }
-        {
-          const float d[3] = {X1.y, Y.y, Z.y};
-          const float e[3] = {X1.z, Y.z, Z.z};
-          a1.update(X1.x * qyz, d, e);
-        }
+        const f2 Q = f2{XA.x, XA.y} * qyz;
+        const f2 d[3] = {f2{XA.z, XA.w}, f2{Y.y, Y.y}, f2{Z.y, Z.y}};
+        const f2 e[3] = {f2{XB.x, XB.y}, f2{Y.z, Y.z}, f2{Z.z, Z.z}};
+        acc.update(Q, d, e);
       }
     }
 
     float v0[20], v1[20];
     const float m_f = (float)m;                    // utils/tf_util.py:722
-    finish(a0, nrows, has_masked, m_f, w, v0);
-    finish(a1, nrows, has_masked, m_f, w, v1);
+    finish(pick(acc, 0), nrows, has_masked, m_f, w, v0);
+    finish(pick(acc, 1), nrows, has_masked, m_f, w, v1);
 
     // L2 normalisation over the 512 Gaussians, per channel (utils/tf_util.py:738-740)
     float part[20];
