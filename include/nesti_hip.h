@@ -87,8 +87,8 @@ int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev,
 
 /* utils/pcpnet_dataset.py:286-343 __getitem__ (center='point', use_pca=False,
  * point_tuple=1) for M query points of one cloud, on the GPU:
- *   cloud_dev [N,3] f32; query_idx_dev [M] int32 (NULL = 0..M-1, the 'full'
- *   sampler utils/pcpnet_dataset.py:41-55); r_abs[S] = bbdiag*rad as double
+ *   cloud_dev [N,3] f32; query_idx_dev [M] int32 (NULL = points query_row0..query_row0+M-1,
+ *   the 'full' sampler utils/pcpnet_dataset.py:41-55); r_abs[S] = bbdiag*rad as double
  *   (utils/pcpnet_dataset.py:282); query_row0 = patch row of the first query within
  *   its shape (so the subsample below does not depend on how rows are batched).
  * Ball membership is the fp64 test scipy's cKDTree applies (:304).  When a ball

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void patches_kernel(const PatchParams p) 
 
   const int q = blockIdx.x;
   const int t = threadIdx.x;
-  const int qi = p.query_idx ? p.query_idx[q] : q;
+  const int qi = p.query_idx ? p.query_idx[q] : p.row0 + q;   // 'full' sampler: patch row == point index
   const GridHeader h = *p.header;
   const float cxf = p.cloud[(size_t)qi * 3], cyf = p.cloud[(size_t)qi * 3 + 1], czf = p.cloud[(size_t)qi * 3 + 2];
   const double cx = cxf, cy = cyf, cz = czf;

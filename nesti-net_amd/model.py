@@ -53,8 +53,10 @@ def mups_forward(cfg: NestiConfig, points, n_eff, out_dtype="f32", out_cstride=N
     cs = out_cstride or 20 * S
     out = torch.empty((B, R, R, R, cs), dtype=_TORCH_DT[out_dtype], device=points.device)
     c = cfg.to_c()
-    _lib.check(lib.nesti_mups_forward(ctypes.byref(c), _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(out),
-                                      DTYPES[out_dtype], cs, _lib.stream_ptr(stream)), "nesti_mups_forward")
+    st = stream if stream is not None else torch.cuda.current_stream(points.device)
+    with torch.cuda.device(points.device):
+        _lib.check(lib.nesti_mups_forward(ctypes.byref(c), _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(out),
+                                          DTYPES[out_dtype], cs, ctypes.c_void_p(st.cuda_stream)), "nesti_mups_forward")
     return out
 
 
@@ -110,6 +112,11 @@ class NestiNet:
         nbytes = self.lib.nesti_workspace_bytes(self._handle, int(batch))
         return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
 
+    def _stream(self, stream):
+        """hipStream_t of ``stream`` (default: the current stream of THIS model's device)."""
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(s.cuda_stream)
+
     # -- pieces (tests and the reference-shaped API) ---------------------------------------
     def mups(self, points, n_eff, stream=None):
         """MuPS in the model's internal layout [B, R^3... , cstride] / dtype."""
@@ -122,9 +129,10 @@ class NestiNet:
         E = self.cfg.n_experts
         probs = torch.empty((B, E), dtype=torch.float32, device=self.device)
         expert = torch.empty((B,), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.nesti_gate_forward(self._handle, _lib.ptr(mups), B, _lib.ptr(ws), ws.numel(),
-                                               _lib.ptr(probs), _lib.ptr(expert), _lib.stream_ptr(stream)),
-                   "nesti_gate_forward")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_gate_forward(self._handle, _lib.ptr(mups), B, _lib.ptr(ws), ws.numel(),
+                                                   _lib.ptr(probs), _lib.ptr(expert), self._stream(stream)),
+                       "nesti_gate_forward")
         return probs, expert
 
     def experts(self, mups, expert=None, stream=None):
@@ -139,8 +147,9 @@ class NestiNet:
         else:
             out = torch.zeros((B, 3), dtype=torch.float32, device=self.device)
             ex = expert.to(device=self.device, dtype=torch.int32).contiguous()
-        _lib.check(self.lib.nesti_experts_forward(self._handle, _lib.ptr(mups), _lib.ptr(ex), B, _lib.ptr(ws), ws.numel(),
-                                                  _lib.ptr(out), _lib.stream_ptr(stream)), "nesti_experts_forward")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_experts_forward(self._handle, _lib.ptr(mups), _lib.ptr(ex), B, _lib.ptr(ws), ws.numel(),
+                                                      _lib.ptr(out), self._stream(stream)), "nesti_experts_forward")
         return out
 
     # -- the sess.run equivalent -----------------------------------------------------------
@@ -160,8 +169,10 @@ class NestiNet:
             n_eff_i = n_eff_i.view(B, 1)       # ss_norm_est feeds a (B,) placeholder (models/ss_norm_est.py:30)
         if self.cfg.arch == ARCH_SINGLE:       # single tower, no gate: n_pred only (test_n_est.py:136-141)
             normals = out[0] if out is not None else torch.empty((B, 3), dtype=torch.float32, device=self.device)
-            _lib.check(self.lib.nesti_forward(self._handle, _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(ws), ws.numel(),
-                                              _lib.ptr(normals), None, None, _lib.stream_ptr(stream)), "nesti_forward")
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.nesti_forward(self._handle, _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(ws),
+                                                  ws.numel(), _lib.ptr(normals), None, None, self._stream(stream)),
+                           "nesti_forward")
             return normals, None, None
         if out is None:
             normals = torch.empty((B, 3), dtype=torch.float32, device=self.device)
@@ -169,9 +180,10 @@ class NestiNet:
             probs = torch.empty((B, E), dtype=torch.float32, device=self.device)
         else:
             normals, expert, probs = out
-        _lib.check(self.lib.nesti_forward(self._handle, _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(ws), ws.numel(),
-                                          _lib.ptr(normals), _lib.ptr(expert), _lib.ptr(probs),
-                                          _lib.stream_ptr(stream)), "nesti_forward")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_forward(self._handle, _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(ws), ws.numel(),
+                                              _lib.ptr(normals), _lib.ptr(expert), _lib.ptr(probs),
+                                              self._stream(stream)), "nesti_forward")
         return normals, expert, probs
 
     __call__ = forward

@@ -61,9 +61,10 @@ class CloudPatches:
     def build_grid(self, stream=None):
         """(Re)build the uniform search grid on the device -- the cKDTree construction of the
         reference (``utils/pcpnet_dataset.py:37``).  Asynchronous on ``stream``."""
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.nesti_patches_grid(ctypes.byref(self._c), _lib.ptr(self.cloud), self.n_points, self._r,
-                                                   _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr(stream)),
+                                                   _lib.ptr(self._ws), self._ws.numel(), ctypes.c_void_p(st.cuda_stream)),
                        "nesti_patches_grid")
 
     def build(self, first, count, want_idx=False, out=None, stream=None):
@@ -74,10 +75,8 @@ class CloudPatches:
         [count,S] when ``want_idx``).  The subsample key uses the global row ``first + i`` so
         results do not depend on batching."""
         S, P = self.cfg.n_scales, self.cfg.num_point
-        if self.pidx is not None:
-            qidx = self.pidx[first:first + count].contiguous()
-        else:
-            qidx = torch.arange(first, first + count, dtype=torch.int32, device=self.device)
+        # sparse: <shape>.pidx rows; full: NULL -> the kernel uses point index = patch row
+        qidx = self.pidx[first:first + count].contiguous() if self.pidx is not None else None
         if out is None:
             points = torch.empty((count, S * P, 3), dtype=torch.float32, device=self.device)
             n_eff = torch.empty((count, S), dtype=torch.int32, device=self.device)
@@ -85,10 +84,13 @@ class CloudPatches:
             points, n_eff = out
         nbr = torch.empty((count, S * P), dtype=torch.int32, device=self.device) if want_idx else None
         n_ball = torch.empty((count, S), dtype=torch.int32, device=self.device) if want_idx else None
-        _lib.check(self.lib.nesti_patches_query(
-            ctypes.byref(self._c), _lib.ptr(self.cloud), self.n_points, _lib.ptr(qidx), count, self._r,
-            ctypes.c_uint64(self.seed), ctypes.c_int(first), _lib.ptr(points), _lib.ptr(n_eff), _lib.ptr(nbr),
-            _lib.ptr(n_ball), _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr(stream)), "nesti_patches_query")
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_patches_query(
+                ctypes.byref(self._c), _lib.ptr(self.cloud), self.n_points, _lib.ptr(qidx), count, self._r,
+                ctypes.c_uint64(self.seed), ctypes.c_int(first), _lib.ptr(points), _lib.ptr(n_eff), _lib.ptr(nbr),
+                _lib.ptr(n_ball), _lib.ptr(self._ws), self._ws.numel(), ctypes.c_void_p(st.cuda_stream)),
+                "nesti_patches_query")
         if want_idx:
             return points, n_eff, nbr, n_ball
         return points, n_eff
