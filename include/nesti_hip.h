@@ -162,6 +162,16 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
                   int B, void* ws_dev, size_t ws_bytes, float* normals_out_dev,
                   int32_t* expert_out_dev, float* probs_out_dev, void* stream);
 
+/* ---- text I/O of the file seam (host only) ------------------------------------------------
+ * np.loadtxt(<shape>.xyz).astype('float32') (utils/pcpnet_dataset.py:250): call with out == NULL for
+ * the shape, then with a [n_rows, take_cols] float32 buffer.  Empty lines and '#' comments are skipped. */
+int nesti_read_text_matrix(const char* path, float* out, int64_t cap_rows, int take_cols,
+                           int64_t* n_rows, int* n_cols);
+/* np.savetxt(path, a) with the default '%.18e' format (test_n_est_w_experts.py:182-183, 187-188). */
+int nesti_write_text_f32(const char* path, const float* data, int64_t rows, int cols);
+/* np.savetxt(path, a.astype(int), fmt='%i') (test_n_est_w_experts.py:185-186). */
+int nesti_write_text_i32(const char* path, const int32_t* data, int64_t rows);
+
 /* ---- measurement support (bench.py's roofline leg; no reference counterpart) ------------
  * nesti_profile_enable(1) makes every kernel launch of the forward path record a pair of
  * hipEvents on its stream; nesti_profile_read() synchronises on them and returns, per

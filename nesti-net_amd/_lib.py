@@ -46,6 +46,10 @@ SIGNATURES = {
     "nesti_gate_forward": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
     "nesti_experts_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "nesti_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "nesti_read_text_matrix": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64, _i, ctypes.POINTER(ctypes.c_int64),
+                                    ctypes.POINTER(_i)]),
+    "nesti_write_text_f32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64, _i]),
+    "nesti_write_text_i32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64]),
     "nesti_profile_enable": (_i, [_i]),
     "nesti_profile_read": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     "nesti_model_macs": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
