@@ -37,7 +37,8 @@ enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2 };
 /* which graph nesti_model_create builds */
 enum {
   NESTI_ARCH_EXPERTS = 0, /* models/experts_n_est.py:40-108  (MoE, the hot path)    */
-  NESTI_ARCH_SINGLE = 1   /* models/ss_norm_est.py:35-92     (BASELINE config 0)    */
+  NESTI_ARCH_SINGLE = 1,  /* models/ss_norm_est.py:35-92     (BASELINE config 0)    */
+  NESTI_ARCH_MULTI = 2    /* models/ms_norm_est.py:45-140    (multi-scale ablation) */
 };
 
 /* Hyper-parameters the reference reads from parameters.p / gmm.p
@@ -157,7 +158,7 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
  * (test_n_est_w_experts.py:142-152) with top-1 routing:
  *   points_dev [B,S*P,3] f32, n_eff_dev [B,S] int32 ->
  *   normals_out_dev [B,3] f32, expert_out_dev [B] int32, probs_out_dev [B,E] f32.
- * For NESTI_ARCH_SINGLE only normals are produced (expert/probs may be NULL). */
+ * For NESTI_ARCH_SINGLE / NESTI_ARCH_MULTI only normals are produced (expert/probs may be NULL). */
 int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev,
                   int B, void* ws_dev, size_t ws_bytes, float* normals_out_dev,
                   int32_t* expert_out_dev, float* probs_out_dev, void* stream);

@@ -8,7 +8,7 @@ from typing import Dict, List
 MAX_SCALES = 4
 MAX_EXPERTS = 8
 DTYPES = {"f32": 0, "bf16": 1, "f16": 2}
-ARCH_EXPERTS, ARCH_SINGLE = 0, 1
+ARCH_EXPERTS, ARCH_SINGLE, ARCH_MULTI = 0, 1, 2
 
 # train_n_est_w_experts.py:62 (JSON-in-JSON there; plain dict here)
 TRAINED_EXPERT_DICT = {0: [0], 1: [0], 2: [1], 3: [1], 4: [2], 5: [2], 6: [0, 1, 2]}

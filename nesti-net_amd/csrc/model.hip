@@ -223,20 +223,28 @@ struct Builder {
     T.n_out = g.cfg.n_experts;
   }
 
-  // ss_norm_est.get_model (models/ss_norm_est.py:35-92): one scale, one tower, no gate.  Dropout
-  // (:76-85) is the identity at inference.  The 2^3 x 1536 feature map is flattened voxel-major
-  // (tf.reshape, :66) into fc1, which here is an FC over a flattened view of the same buffer.
+  // The single-tower ablations: ss_norm_est.get_model (models/ss_norm_est.py:35-92; one scale, 4^3 kernels
+  // [3,5], scopes 'inception<L>') and ms_norm_est.get_model (models/ms_norm_est.py:45-140; S scales
+  // concatenated on channels, 4^3 kernels [3,4], scopes 'inception_s<S-1>_l_<L>').  Dropout is the identity at
+  // inference.  The 2^3 x 1536 feature map is flattened voxel-major (tf.reshape) into fc1, which here is an FC
+  // over a flattened view of the same buffer.
   void build_single() {
     Tower& T = g.experts[0];
     init_tower(T);
+    const bool multi = g.cfg.arch == NESTI_ARCH_MULTI;
+    const int S = g.cfg.n_scales;
     ChanMap m; m.C = g.mups_cstride;
-    for (int c = 0; c < 20; ++c) m.pos.push_back(c);
-    int b = inception(T, "inception1", 0, m, 128, 3, 5, 3, &m);
-    b = inception(T, "inception2", b, m, 256, 3, 5, 3, &m);
-    b = inception(T, "inception3", b, m, 256, 3, 5, 3, &m);
+    for (int c = 0; c < 20 * S; ++c) m.pos.push_back(c);
+    auto name = [&](int layer) {
+      return multi ? "inception_s" + std::to_string(S - 1) + "_l_" + std::to_string(layer) : "inception" + std::to_string(layer);
+    };
+    const int k1_small = multi ? 4 : 5;
+    int b = inception(T, name(1), 0, m, 128, 3, 5, 3, &m);
+    b = inception(T, name(2), b, m, 256, 3, 5, 3, &m);
+    b = inception(T, name(3), b, m, 256, 3, 5, 3, &m);
     b = maxpool(T, b, m, 3);
-    b = inception(T, "inception5", b, m, 512, 3, 5, 2, &m);
-    b = inception(T, "inception6", b, m, 512, 3, 5, 2, &m);
+    b = inception(T, name(5), b, m, 512, 3, k1_small, 2, &m);
+    b = inception(T, name(6), b, m, 512, 3, k1_small, 2, &m);
     b = maxpool(T, b, m, 2);
     ChanMap flat; flat.C = 8 * m.C;
     for (int v = 0; v < 8; ++v)
@@ -267,7 +275,8 @@ struct Builder {
 };
 
 int build_graph(const nesti_config_t* cfg, Graph* g) {
-  if (cfg->arch != NESTI_ARCH_EXPERTS && cfg->arch != NESTI_ARCH_SINGLE) NESTI_FAIL("unknown arch");
+  if (cfg->arch != NESTI_ARCH_EXPERTS && cfg->arch != NESTI_ARCH_SINGLE && cfg->arch != NESTI_ARCH_MULTI)
+    NESTI_FAIL("unknown arch");
   if (cfg->arch == NESTI_ARCH_SINGLE && cfg->n_scales != 1) NESTI_FAIL("NESTI_ARCH_SINGLE (ss_norm_est) takes exactly one scale");
   if (cfg->grid_n != 8) NESTI_FAIL("only the 8^3 Gaussian grid is implemented");
   if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("bad n_scales");
@@ -282,7 +291,7 @@ int build_graph(const nesti_config_t* cfg, Graph* g) {
   g->layers.clear();
   Builder b(*g);
   g->gate = Tower();
-  if (cfg->arch == NESTI_ARCH_SINGLE) {
+  if (cfg->arch == NESTI_ARCH_SINGLE || cfg->arch == NESTI_ARCH_MULTI) {
     g->cfg.n_experts = 1;
     g->experts.assign(1, Tower());
     b.build_single();
@@ -726,7 +735,7 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride, st);
   prof_end(NESTI_PROF_MUPS, st);
   if (rcm) return 1;
-  if (m->graph.cfg.arch == NESTI_ARCH_SINGLE)   // ss_norm_est: the tower's output IS n_pred (test_n_est.py:136-141)
+  if (m->graph.cfg.arch != NESTI_ARCH_EXPERTS)   // single-tower ablations: the tower's output IS n_pred (test_n_est.py:136-141)
     return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, nullptr, nullptr, normals_out_dev, st);
   float* probs = probs_out_dev ? probs_out_dev : (float*)(ws + L.probs);
   int32_t* expert = expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert);

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .config import ARCH_SINGLE, DTYPES, NestiConfig
+from .config import ARCH_EXPERTS, DTYPES, NestiConfig
 
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
 
@@ -140,7 +140,7 @@ class NestiNet:
         expert=[B] int32 -> top-1 routed normals [B,3]."""
         B = mups.shape[0]
         ws = self.reserve(B)
-        E = 1 if self.cfg.arch == ARCH_SINGLE else self.cfg.n_experts
+        E = 1 if self.cfg.arch != ARCH_EXPERTS else self.cfg.n_experts
         if expert is None:
             out = torch.empty((E, B, 3), dtype=torch.float32, device=self.device)
             ex = None
@@ -167,7 +167,7 @@ class NestiNet:
         n_eff_i = n_eff if (n_eff.dtype == torch.int32 and n_eff.is_contiguous()) else n_eff.to(torch.int32).contiguous()
         if n_eff_i.dim() == 1:
             n_eff_i = n_eff_i.view(B, 1)       # ss_norm_est feeds a (B,) placeholder (models/ss_norm_est.py:30)
-        if self.cfg.arch == ARCH_SINGLE:       # single tower, no gate: n_pred only (test_n_est.py:136-141)
+        if self.cfg.arch != ARCH_EXPERTS:      # single tower, no gate: n_pred only (test_n_est.py:136-141)
             normals = out[0] if out is not None else torch.empty((B, 3), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.nesti_forward(self._handle, _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(ws),

@@ -150,6 +150,25 @@ def single_forward(mups, W, dtype=torch.float64):
     return fc(g, W, "fc4", dtype, bn=False, relu=False)            # :86
 
 
+def multi_forward(mups, W, n_scales, dtype=torch.float64):
+    """``ms_norm_est.get_model`` after the 3DmFV (``models/ms_norm_est.py:74-140``): MuPS
+    [B,8,8,8,20*S] -> normal [B,3].  Scopes carry the last scale index (``'inception_s'+str(s)``, ``:79``)."""
+    sc = "inception_s%d_l_" % (n_scales - 1)
+    x = _t(mups, dtype)
+    x = inception(x, W, sc + "1", 3, 5, dtype)
+    x = inception(x, W, sc + "2", 3, 5, dtype)
+    x = inception(x, W, sc + "3", 3, 5, dtype)
+    x = max_pool3d_2(x)
+    x = inception(x, W, sc + "5", 3, 4, dtype)                     # :87-89  kernel_sizes=[3, 4]
+    x = inception(x, W, sc + "6", 3, 4, dtype)
+    x = max_pool3d_2(x)
+    g = x.reshape(x.shape[0], -1)
+    g = fc(g, W, "fc1", dtype)
+    g = fc(g, W, "fc2", dtype)
+    g = fc(g, W, "fc3", dtype)
+    return fc(g, W, "fc4", dtype, bn=False, relu=False)
+
+
 def moe_forward(mups, W, expert_dict=None, dtype=torch.float64, top1_only=False):
     """``get_model`` after MuPS (``models/experts_n_est.py:78-108``) plus the
     driver's arg-max / select (``test_n_est_w_experts.py:150-152``).

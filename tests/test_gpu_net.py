@@ -212,3 +212,24 @@ def test_single_scale_model_matches_oracle(gpu_device):
     net16 = NestiNet(cfg, W, dtype="bf16", device=gpu_device, max_batch=9)
     n16, _, _ = net16(torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device))
     assert np.all(1 - _cos(n16.cpu().numpy(), ref) < 2e-3)
+
+
+def test_multi_scale_ablation_matches_oracle(gpu_device):
+    """ms_norm_est (N4): S scales concatenated, one tower, 4^3 kernels [3,4]."""
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import ARCH_MULTI, NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from oracle import mups_ref, net_ref
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid20k" in p][0])
+    cfg = NestiConfig(n_experts=1, expert_dict={0: [0, 1, 2]}, arch=ARCH_MULTI)
+    W = weights.synthetic_weights(cfg)
+    assert W["inception_s2_l_1_conv1/weights"].shape == (1, 1, 1, 60, 128)
+    assert W["inception_s2_l_5_conv3/weights"].shape == (4, 4, 4, 512, 256)
+    pts, n_eff = g["points"][:7], g["n_eff"][:7]
+    net = NestiNet(cfg, W, dtype="f32", device=gpu_device, max_batch=7)
+    normals, _, _ = net(torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device))
+    torch.cuda.synchronize()
+    ref = net_ref.multi_forward(mups_ref.mups_assemble(pts, n_eff, 3), W, 3, dtype=torch.float64).numpy()
+    c = _cos(normals.cpu().numpy(), ref)
+    print("ms_norm_est min cosine (f32):", c.min())
+    assert np.all(1 - c < COS_TOL_F32)
