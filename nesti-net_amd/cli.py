@@ -16,7 +16,7 @@ import torch
 
 from . import textio
 from . import weights as wts
-from .config import NestiConfig
+from .config import ARCH_EXPERTS, ARCH_MULTI, ARCH_SINGLE, NestiConfig
 from .pipeline import NormalEstimator
 from .provider import PointcloudPatchDataset
 
@@ -40,8 +40,10 @@ def build_parser():
 
 def main(argv=None):
     FLAGS = build_parser().parse_args(argv)
-    if FLAGS.model != "experts_n_est":
-        raise SystemExit("only --model experts_n_est (the mixture-of-experts hot path) is implemented")
+    archs = {"experts_n_est": ARCH_EXPERTS, "ss_norm_est": ARCH_SINGLE, "ms_norm_est": ARCH_MULTI}
+    if FLAGS.model not in archs:
+        raise SystemExit("--model must be one of %s (ms_sw_n_est, the switching ablation, is out of scope)" % sorted(archs))
+    arch = archs[FLAGS.model]
     results_path = FLAGS.results_path
     base = os.getcwd()
     pc_path = FLAGS.dataset_path if FLAGS.dataset_path is not None else os.path.join(base, "data/" + FLAGS.dataset_name + "/")
@@ -66,10 +68,16 @@ def main(argv=None):
         cfg, W = tf_ckpt.load_reference_model(results_path)
     elif FLAGS.synthetic_weights:
         cfg = NestiConfig()
+        if arch == ARCH_SINGLE:      # test_n_est.py drives the single-tower ablations the same way (:59-166)
+            cfg = NestiConfig(patch_radius=[0.05], n_experts=1, expert_dict={0: [0]}, arch=arch)
+        elif arch == ARCH_MULTI:
+            cfg = NestiConfig(n_experts=1, expert_dict={0: [0, 1, 2]}, arch=arch)
         printout("No %s: using synthetic weights (seed %d)" % (model_file, wts.WEIGHT_SEED))
         W = wts.synthetic_weights(cfg)
     else:
         raise SystemExit("%s not found (pass --synthetic_weights to run without a trained model)" % model_file)
+    if cfg.arch != arch:
+        raise SystemExit("--model %s does not match the trained model in %s" % (FLAGS.model, results_path))
     device = "cuda:%d" % FLAGS.gpu
     est = NormalEstimator(cfg, W, dtype=FLAGS.dtype, device=device, batch=max(FLAGS.batch_size, 4096), n_streams=2)
     printout("Model restored.")
@@ -83,6 +91,8 @@ def main(argv=None):
         # byte-identical to the reference's np.savetxt calls (test_n_est_w_experts.py:182-188), ~6x faster
         textio.write_f32(os.path.join(output_dir, name + ".normals"), normals.cpu().numpy())
         printout("saved normals for " + name)
+        if expert is None:           # single-tower ablations write .normals only (test_n_est.py:118)
+            continue
         textio.write_i32(os.path.join(output_dir, name + ".experts"), expert.cpu().numpy())
         textio.write_f32(os.path.join(output_dir, name + ".experts_probs"), probs.cpu().numpy())
         printout("saved experts for " + name)

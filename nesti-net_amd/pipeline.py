@@ -5,7 +5,7 @@ query) -> MuPS -> gating -> top-1 expert -> normals.  This is the body of the re
 import numpy as np
 import torch
 
-from .config import NestiConfig
+from .config import ARCH_EXPERTS, NestiConfig
 from .model import NestiNet
 from .provider import CloudPatches
 
@@ -67,6 +67,7 @@ class NormalEstimator:
             probs = torch.empty((count, E), dtype=torch.float32, device=self.device)
         else:
             normals, expert, probs = out
+        single_tower = self.cfg.arch != ARCH_EXPERTS      # ss/ms ablations: normals only
         done, it = 0, 0
         main = torch.cuda.current_stream(self.device)
         if self.n_streams > 1:
@@ -100,6 +101,8 @@ class NormalEstimator:
             done += take
         for lane in self._lanes:
             main.wait_stream(lane[0])                 # results are ordered on the caller's stream again
+        if single_tower:
+            return normals, None, None
         return normals, expert, probs
 
     def estimate(self, pts, pidx=None):
@@ -107,4 +110,6 @@ class NormalEstimator:
         cloud = self.prepare(np.asarray(pts, dtype=np.float32), pidx)
         normals, expert, probs = self.run(cloud)
         torch.cuda.synchronize(self.device)
+        if expert is None:
+            return normals.cpu().numpy(), None, None
         return normals.cpu().numpy(), expert.cpu().numpy(), probs.cpu().numpy()

@@ -122,3 +122,17 @@ def test_two_stream_batches_match_single_stream(gpu_device):
     b = two.estimate(pts, pidx=np.arange(0, 5000, 4))
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_cli_single_scale_model(dataset_dir, tmp_path, gpu_device):
+    """--model ss_norm_est (the reference's test_n_est.py path, BASELINE config 0): .normals only."""
+    from nesti_net_amd.cli import main
+    results = str(tmp_path / "log_ss") + os.sep
+    os.makedirs(results)
+    rc = main(["--results_path", results, "--model", "ss_norm_est", "--dataset_name", "synth", "--dataset_path", dataset_dir,
+               "--testset", "testset.txt", "--sparse_patches", "1", "--synthetic_weights", "--dtype", "bf16"])
+    assert rc == 0
+    out = os.path.join(results, "synth_results")
+    normals = np.loadtxt(os.path.join(out, "shapeA.normals"))
+    assert normals.shape == (len(range(0, 3000, 7)), 3) and np.all(np.isfinite(normals))
+    assert not os.path.exists(os.path.join(out, "shapeA.experts"))
