@@ -101,6 +101,8 @@ def main():
                     help="alternate consecutive batches between this many HIP streams (2 is ~3% faster, but kernels of the two "
                          "streams overlap, so per-launch durations no longer describe one kernel)")
     ap.add_argument("--graph", action="store_true", help="replay the forward of full batches from a captured hipGraph")
+    ap.add_argument("--debug-single-device", action="store_true",
+                    help="testing aid: every rank uses cuda:0 and the gloo backend (exercises the N>1 logic on a 1-GPU box)")
     ap.add_argument("--uncalibrated-gate", action="store_true", help="raw synthetic gate (routes ~everything to one expert)")
     args = ap.parse_args()
 
@@ -110,12 +112,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if args.debug_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_pg = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.debug_single_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     cfg = NestiConfig()
     W = weights.synthetic_weights(cfg)
@@ -129,7 +136,8 @@ def main():
         sp, sn = cp.build(0, min(512, args.points))
         W = calibrate_gate(cfg, W, sp, sn, device=dev)
         del cp, sp, sn
-    est = NormalEstimator(cfg, W, dtype=args.dtype, device=dev, batch=min(args.batch, args.points), use_graph=args.graph,
+    max_shard = max(ndist.max_shard(len(p), world) for p, _ in clouds_np)      # rows of one cloud on one rank
+    est = NormalEstimator(cfg, W, dtype=args.dtype, device=dev, batch=min(args.batch, max_shard), use_graph=args.graph,
                           n_streams=args.streams)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
     lib = _lib.load()
