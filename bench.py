@@ -84,6 +84,60 @@ def cpu_baseline(cfg, W, pts):
                       % (n_patch, t_patch * 1e3, n_mups, t_mups * 1e3, n_net, cores, t_net * 1e3)}
 
 
+def mups_only(args, cfg, dev):
+    """Config 1: 100k queries -> patches (HIP ball query) -> MuPS f32 [B,8,8,8,60].  MuPS is fp32-VALU bound
+    (SURVEY.md 8(d)): ~55 lane-ops x 256 threads per patch row; HBM bytes = 122 880 written + 18 432 read per query."""
+    from nesti_net_amd.model import mups_forward
+    from nesti_net_amd.provider import CloudPatches
+    pts, _ = synth.make_cloud("ellipsoid", n=args.points, seed=1234)
+    cp = CloudPatches(pts, cfg, device=dev)
+    B = min(args.batch, 16384, args.points)
+    lib = _lib.load()
+    res_rows = 0
+
+    def step():
+        nonlocal res_rows
+        done, rows = 0, 0
+        while done < args.points:
+            take = min(B, args.points - done)
+            p, n = cp.build(done, take)
+            out = mups_forward(cfg, p, n, out_dtype="f32")
+            rows += int(n.sum().item()) if done == 0 else 0
+            done += take
+        res_rows = rows
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    lib.nesti_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    ms = (ctypes.c_double * 4)()
+    nl = (ctypes.c_longlong * 4)()
+    lib.nesti_profile_read(ms, nl)
+    lib.nesti_profile_enable(0)
+    q = args.points * args.steps
+    mups_s = ms[1] / 1e3
+    rows_per_q = res_rows / max(1, min(B, args.points)) + cfg.n_scales       # + the unmasked row n_eff per scale
+    valu_ops = 55.0 * 256 * rows_per_q * q                                     # lane-ops, see csrc/mups.hip
+    print(json.dumps({
+        "metric": "MuPS queries/sec (patch extraction + MuPS only)", "value": q / el, "unit": "queries/sec", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 1: %d-point ellipsoid, 3 scales, 8^3 grid, f32 output" % args.points,
+                   "mean_patch_rows_per_query": rows_per_q},
+        "roofline": {"bound": "valu", "kernel": "mups_kernel", "achieved": valu_ops / mups_s / 1e12, "peak": 78.6,
+                     "unit": "Tlane-op/s (fp32 VALU issue: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz)",
+                     "frac": valu_ops / mups_s / 1e12 / 78.6,
+                     "hbm_GBps": q * (122880 + 18432 + 12) / mups_s / 1e9, "hbm_frac_of_8TBps": q * 141324 / mups_s / 8e12,
+                     "kernel_ms_per_step": {"mups": ms[1] / args.steps, "patches": ms[3] / args.steps}}}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +154,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="alternate consecutive batches between this many HIP streams (2 is ~3% faster, but kernels of the two "
                          "streams overlap, so per-launch durations no longer describe one kernel)")
+    ap.add_argument("--mups-only", action="store_true",
+                    help="BASELINE config 1: time only patch extraction + the MuPS kernel (f32 [B,8,8,8,60] output); prints its "
+                         "own JSON line with the VALU / HBM roofline fractions (not the headline workload)")
     ap.add_argument("--graph", action="store_true", help="replay the forward of full batches from a captured hipGraph")
     ap.add_argument("--debug-single-device", action="store_true",
                     help="testing aid: every rank uses cuda:0 and the gloo backend (exercises the N>1 logic on a 1-GPU box)")
@@ -125,6 +182,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     cfg = NestiConfig()
+    if args.mups_only:
+        return mups_only(args, cfg, dev)
     W = weights.synthetic_weights(cfg)
     clouds_np = make_clouds(args.stream_clouds, args.points, stream=True) if args.stream_clouds else make_clouds(world, args.points)
     if not args.uncalibrated_gate:
