@@ -55,6 +55,26 @@ struct Stats {
       sg_sum[c] += v;
     }
   }
+  // two patch rows at once: the 26 running max/min become 3-input v_max3_f32 / v_min3_f32, halving their count
+  __device__ __forceinline__ void update2(f2 Qa, const f2 (&da)[3], const f2 (&ea)[3], f2 Qb, const f2 (&db)[3],
+                                          const f2 (&eb)[3]) {
+    sq += Qa;
+    sq += Qb;
+    mq = __builtin_elementwise_max(__builtin_elementwise_max(mq, Qa), Qb);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f2 ma = Qa * da[c], mb = Qb * db[c];
+      mu_max[c] = __builtin_elementwise_max(__builtin_elementwise_max(mu_max[c], ma), mb);
+      mu_min[c] = __builtin_elementwise_min(__builtin_elementwise_min(mu_min[c], ma), mb);
+      mu_sum[c] += ma;
+      mu_sum[c] += mb;
+      const f2 va = Qa * ea[c], vb = Qb * eb[c];
+      sg_max[c] = __builtin_elementwise_max(__builtin_elementwise_max(sg_max[c], va), vb);
+      sg_min[c] = __builtin_elementwise_min(__builtin_elementwise_min(sg_min[c], va), vb);
+      sg_sum[c] += va;
+      sg_sum[c] += vb;
+    }
+  }
 };
 
 // raw statistics of ONE of the two Gaussians
@@ -191,16 +211,27 @@ __global__ __launch_bounds__(kThreads) void mups_kernel(const float* __restrict_
       }
       __syncthreads();
       const int cnt = min(kChunk, nrows - c0);
-      for (int nl = 0; nl < cnt; ++nl) {
+      auto row_terms = [&](int nl, f2* Q, f2 (&d)[3], f2 (&e)[3]) __attribute__((always_inline)) {
         const float4 XA = stage_x[nl][2 * i0];
         const float4 XB = stage_x[nl][2 * i0 + 1];
         const float4 Y = stage_yz[nl][j];
         const float4 Z = stage_yz[nl][kR + k];
         asm volatile("" ::"v"(Y.w), "v"(Z.w));   // keep these ds_read_b128: a 12-byte ds_read_b96 costs 8 LDS cycles, not 4
         const float qyz = Y.x * Z.x;
-        const f2 Q = f2{XA.x, XA.y} * qyz;
-        const f2 d[3] = {f2{XA.z, XA.w}, f2{Y.y, Y.y}, f2{Z.y, Z.y}};
-        const f2 e[3] = {f2{XB.x, XB.y}, f2{Y.z, Y.z}, f2{Z.z, Z.z}};
+        *Q = f2{XA.x, XA.y} * qyz;
+        d[0] = f2{XA.z, XA.w}; d[1] = f2{Y.y, Y.y}; d[2] = f2{Z.y, Z.y};
+        e[0] = f2{XB.x, XB.y}; e[1] = f2{Y.z, Y.z}; e[2] = f2{Z.z, Z.z};
+      };
+      int nl = 0;
+      for (; nl + 1 < cnt; nl += 2) {
+        f2 Qa, Qb, da[3], ea[3], db[3], eb[3];
+        row_terms(nl, &Qa, da, ea);
+        row_terms(nl + 1, &Qb, db, eb);
+        acc.update2(Qa, da, ea, Qb, db, eb);
+      }
+      if (nl < cnt) {
+        f2 Q, d[3], e[3];
+        row_terms(nl, &Q, d, e);
         acc.update(Q, d, e);
       }
     }
