@@ -363,6 +363,76 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
     return;
   }
 
+  if (p.mp_mode != 0 && !second) {
+    // Fused 2^3 stride-2 max-pool (and optionally the full-resolution store): per 64-column half the ACTIVATED
+    // values go through the fp32 LDS tile [512][64 (+4 pad)]; a thread then reduces whole 2x2x2 cells of one
+    // 4-channel group.  max(relu(x + b)) is taken on the final values, exactly like pooling the stored tensor.
+    unsigned char* mp_b = reinterpret_cast<unsigned char*>(p.mp_out);
+    const int Vo = V >> 3, So = S >> 1, log2So = log2S - 1;
+    auto cvt_store = [&](unsigned char* dst, const float4& v) __attribute__((always_inline)) {
+      if (out_esz == 4) {
+        *reinterpret_cast<float4*>(dst) = v;
+      } else {
+        using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
+        const uint32_t w0 = (uint32_t)E::from_f32(v.x) | ((uint32_t)E::from_f32(v.y) << 16);
+        const uint32_t w1 = (uint32_t)E::from_f32(v.z) | ((uint32_t)E::from_f32(v.w) << 16);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
+      }
+    };
+    auto mp_half = [&](auto NH) __attribute__((always_inline)) {
+      constexpr int nh = decltype(NH)::value;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+          const int ni = nh * 2 + n2;
+          const int col = n2 * 32 + (lane & 31);
+          const float bv = bias[ni * 32 + (lane & 31)];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            float v = acc[mi][ni][r] + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = v;
+          }
+        }
+      __syncthreads();
+      if (p.mp_mode == 2) {   // full-resolution rows, 16 consecutive lanes = one 64-channel row segment
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int item = it * kThreads + tid;
+          const int row = item >> 4, cg = item & 15;
+          const long long gr = r0 + row;
+          if (gr < total_rows)
+            cvt_store(out_b + (gr * p.out_cstride + out_col0 + nh * 64 + cg * 4) * out_esz,
+                      *reinterpret_cast<const float4*>(smem + row * kPoolStride + cg * 16));
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {   // 64 pooled rows x 16 channel groups
+        const int item = it * kThreads + tid;
+        const int orow = item >> 4, cg = item & 15;
+        const int pt_l = orow >> (log2V - 3), cell = orow & (Vo - 1);
+        const int cz = cell >> (2 * log2So), cy = (cell >> log2So) & (So - 1), cx = cell & (So - 1);
+        const int base = (pt_l << log2V) + ((((2 * cz) << log2S) + 2 * cy) << log2S) + 2 * cx;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+          const int row = base + ((a >> 2) << (2 * log2S)) + (((a >> 1) & 1) << log2S) + (a & 1);
+          const float4 v = *reinterpret_cast<const float4*>(smem + row * kPoolStride + cg * 16);
+          m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+        const long long go = (r0 >> 3) + orow;
+        if (go < (total_rows >> 3))
+          cvt_store(mp_b + (go * p.mp_cstride + out_col0 + nh * 64 + cg * 4) * out_esz, m);
+      }
+      __syncthreads();
+    };
+    mp_half(std::integral_constant<int, 0>{});
+    if constexpr (TN == 128) mp_half(std::integral_constant<int, 1>{});
+    return;
+  }
+
   // plain epilogue: bias + ReLU, transpose through a wave-private LDS scratch, 16-B stores
   unsigned char* scratch = smem + wave * 8192;
   const int seg = 64 * out_esz;                 // bytes of one 64-channel row segment
@@ -400,8 +470,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 
 template <int TN, bool KPIPE>
 constexpr size_t lds_bytes() {
-  return KPIPE ? (size_t)2 * kABytes + 2 * TN * kRowBytes                 // 160 KiB at TN = 128
-               : (size_t)kABytes + 4 * TN * kRowBytes + kRowBytes;       // 4 weight slots + zero row
+  constexpr size_t kPoolTile = (size_t)kTileM * kPoolStride + 16;         // fp32 pooling tile of the epilogues
+  constexpr size_t loop = KPIPE ? (size_t)2 * kABytes + 2 * TN * kRowBytes         // 160 KiB at TN = 128
+                                : (size_t)kABytes + 4 * TN * kRowBytes + kRowBytes; // 4 weight slots + zero row
+  return loop > kPoolTile ? loop : kPoolTile;
 }
 
 template <int DT, int TN, bool KPIPE>
@@ -435,6 +507,7 @@ int launch_dt(const ConvParams& p, int TN, hipStream_t stream) {
 int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream) {
   if (p.m_tiles <= 0 || p.n_tiles <= 0) return 0;
   if (p.pool_k > 1 && p.n_taps != 1) NESTI_FAIL("launch_conv: fused pooling needs a 1x1x1 layer");
+  if (p.mp_mode != 0 && (p.log2S < 1 || !p.mp_out)) NESTI_FAIL("launch_conv: fused max-pool needs a volume >= 2^3 and an output");
   if (p.pool_k > 1 && !((p.log2S == 3 && p.pool_k == 3) || (p.log2S == 2 && (p.pool_k == 2 || p.pool_k == 3)) ||
                         (p.log2S == 1 && p.pool_k == 2)))
     NESTI_FAIL("launch_conv: fused pooling supports (S,k) in {(8,3),(4,3),(4,2),(2,2)}");

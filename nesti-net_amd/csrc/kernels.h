@@ -34,6 +34,11 @@ struct ConvParams {
   int split_tile;      // == n_tiles for an ordinary layer
   int out_coff2;
   int pool_k;
+  // fused tf.nn.max_pool3d 2^3 stride 2 (utils/tf_util.py:424-428) for the FIRST tile group: 1 = write only the pooled
+  // tensor, 2 = write the full-resolution tensor and the pooled one
+  void* mp_out;        // [points * V/8, mp_cstride], same channel offsets as `out`
+  int mp_cstride;
+  int mp_mode;
   int8_t tap[kMaxTaps][4];   // dz, dy, dx, -
 };
 

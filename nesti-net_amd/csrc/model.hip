@@ -104,6 +104,7 @@ struct Op {
   enum Kind { CONV, MAX } kind;
   int in_buf = 0, in_coff = 0, out_buf = 0, out_coff = 0, out_coff2 = 0;
   int in_cstride = 0;          // 0: the input buffer's channel count; else a flattened view (FC on S^3 x C)
+  int mp_buf = -1, mp_mode = 0; // fused 2^3 max-pool of the first tile group into this buffer (1: pooled only, 2: both)
   int layer = -1;
   int C = 0, k = 0, log2S = 0;
   bool out_f32 = false;
@@ -148,24 +149,43 @@ struct Builder {
 
   // models/experts_n_est.py:294-314.  conv1 and conv4 read the same tensor (avg_pool3d commutes with the
   // 1x1x1 convolution), so they are one launch; conv4's columns are averaged in the kernel epilogue.
+  // then_maxpool: the block is followed by tf_util.max_pool3d 2^3/2 (e.g. models/experts_n_est.py:198).  conv1
+  // stores full resolution (conv2/conv3 read it) AND its pooled tensor, conv2/conv3 store only the pooled tensor
+  // (nobody reads them at full resolution); conv4's columns come out of the avg-pool epilogue at full resolution
+  // and are max-pooled by the small standalone kernel, restricted to their channel range.  Returns the buffer the
+  // next block reads.
   int inception(Tower& T, const std::string& scope, int in_buf, const ChanMap& in, int F, int k0, int k1, int log2S,
-                ChanMap* out_map) {
+                ChanMap* out_map, bool then_maxpool = false) {
     const int H = F / 2;   // int(n_filters/2)  :299
     const int Fp = pad_to(F, kPad), Hp = pad_to(H, kPad);
     const int C = Fp + Hp + Hp + Fp;
     T.bufs.push_back({log2S, C, false});
     const int ob = (int)T.bufs.size() - 1;
+    int pb = -1;
+    if (then_maxpool) {
+      T.bufs.push_back({log2S - 1, C, false});
+      pb = (int)T.bufs.size() - 1;
+    }
     ChanMap c1; c1.C = Fp; for (int i = 0; i < F; ++i) c1.pos.push_back(i);
     conv(T, scope + "_conv1", 1, log2S, in_buf, 0, in, F, ob, 0, true, true, false, false,
          scope + "_conv4", Fp + Hp + Hp, k0);
+    if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 2; }
     conv(T, scope + "_conv2", k0, log2S, ob, 0, c1, H, ob, Fp);
+    if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 1; }
     conv(T, scope + "_conv3", k1, log2S, ob, 0, c1, H, ob, Fp + Hp);
+    if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 1; }
     out_map->pos.clear();
     for (int i = 0; i < F; ++i) out_map->pos.push_back(i);
     for (int i = 0; i < H; ++i) out_map->pos.push_back(Fp + i);
     for (int i = 0; i < H; ++i) out_map->pos.push_back(Fp + Hp + i);
     for (int i = 0; i < F; ++i) out_map->pos.push_back(Fp + Hp + Hp + i);
     out_map->C = C;
+    if (then_maxpool) {
+      Op op; op.kind = Op::MAX; op.in_buf = ob; op.out_buf = pb; op.in_coff = op.out_coff = Fp + Hp + Hp;
+      op.C = Fp; op.log2S = log2S;
+      T.ops.push_back(op);
+      return pb;
+    }
     return ob;
   }
 
@@ -211,13 +231,10 @@ struct Builder {
     const std::string s = "gating_conv";
     int b = inception(T, "inception1" + s, 0, m, 128, 3, 5, 3, &m);
     b = inception(T, "inception2" + s, b, m, 256, 3, 5, 3, &m);
-    b = inception(T, "inception3" + s, b, m, 256, 3, 5, 3, &m);
-    b = maxpool(T, b, m, 3);
+    b = inception(T, "inception3" + s, b, m, 256, 3, 5, 3, &m, true);    // + maxpool4  :198
     b = inception(T, "inception5" + s, b, m, 512, 2, 4, 2, &m);
-    b = inception(T, "inception6" + s, b, m, 512, 2, 4, 2, &m);
-    b = maxpool(T, b, m, 2);
-    b = inception(T, "inception8" + s, b, m, 512, 1, 2, 1, &m);
-    b = maxpool(T, b, m, 1);
+    b = inception(T, "inception6" + s, b, m, 512, 2, 4, 2, &m, true);    // + maxpool7  :206
+    b = inception(T, "inception8" + s, b, m, 512, 1, 2, 1, &m, true);    // + maxpool9  :211
     T.out_buf = fc_stack(T, b, m, {"fc1noise", "fc2noise", "fc3noise", "fc4noise"}, {1024, 256, 128, g.cfg.n_experts},
                          /*last_relu=*/true);   // relu on fc4: models/experts_n_est.py:174
     T.n_out = g.cfg.n_experts;
@@ -241,11 +258,9 @@ struct Builder {
     const int k1_small = multi ? 4 : 5;
     int b = inception(T, name(1), 0, m, 128, 3, 5, 3, &m);
     b = inception(T, name(2), b, m, 256, 3, 5, 3, &m);
-    b = inception(T, name(3), b, m, 256, 3, 5, 3, &m);
-    b = maxpool(T, b, m, 3);
+    b = inception(T, name(3), b, m, 256, 3, 5, 3, &m, true);
     b = inception(T, name(5), b, m, 512, 3, k1_small, 2, &m);
-    b = inception(T, name(6), b, m, 512, 3, k1_small, 2, &m);
-    b = maxpool(T, b, m, 2);
+    b = inception(T, name(6), b, m, 512, 3, k1_small, 2, &m, true);
     ChanMap flat; flat.C = 8 * m.C;
     for (int v = 0; v < 8; ++v)
       for (size_t c = 0; c < m.pos.size(); ++c) flat.pos.push_back(v * m.C + m.pos[c]);
@@ -263,12 +278,9 @@ struct Builder {
     const std::string s = "Expert_" + std::to_string(i);
     const int F1 = 128 / cnt;   // np.round(128 / divider) under Python-2 integer division  :254
     int b = inception(T, "inception1" + s, 0, m, F1, 3, 5, 3, &m);
-    b = inception(T, "inception2" + s, b, m, 256, 3, 5, 3, &m);
-    b = maxpool(T, b, m, 3);
-    b = inception(T, "inception4" + s, b, m, 256, 2, 4, 2, &m);
-    b = maxpool(T, b, m, 2);
-    b = inception(T, "inception6" + s, b, m, 512, 2, 4, 1, &m);
-    b = maxpool(T, b, m, 1);
+    b = inception(T, "inception2" + s, b, m, 256, 3, 5, 3, &m, true);    // + maxpool3  :261
+    b = inception(T, "inception4" + s, b, m, 256, 2, 4, 2, &m, true);    // + maxpool5  :266
+    b = inception(T, "inception6" + s, b, m, 512, 2, 4, 1, &m, true);    // + maxpool7  :271
     T.out_buf = fc_stack(T, b, m, {"fc1" + s, "fc2" + s, "fc3" + s, "fc4" + s}, {512, 128, 64, 3}, /*last_relu=*/false);
     T.n_out = 3;
   }
@@ -512,6 +524,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       const long long rows = (long long)rc.NB << (3 * d.log2S);
       p.m_tiles = (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
+      if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C; p.mp_mode = op.mp_mode; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       prof_begin(NESTI_PROF_CONV, rc.stream);
       const int rcv = launch_conv(p, dtype, pl.TN, rc.stream);
