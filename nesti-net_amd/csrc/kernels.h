@@ -48,14 +48,11 @@ struct PoolParams {
   const void* in;
   void* out;
   const int32_t* npoints_ptr;
-  const int32_t* point_index;   // gather of INPUT points (avg pool only)
   int npoints;
   int in_cstride, in_coff, out_cstride, out_coff;
   int C;               // channels to process (multiple of 8)
   int log2S;           // input S
-  int k;               // avg: window; max: ignored (2^3 stride 2)
 };
-int launch_avgpool(const PoolParams& p, int dtype, hipStream_t stream);
 int launch_maxpool2(const PoolParams& p, int dtype, hipStream_t stream);
 
 // softmax over the first E logits of each row + first-index arg-max

@@ -189,14 +189,6 @@ struct Builder {
     return ob;
   }
 
-  int maxpool(Tower& T, int in_buf, const ChanMap& m, int log2S) {
-    T.bufs.push_back({log2S - 1, m.C, false});
-    const int ob = (int)T.bufs.size() - 1;
-    Op op; op.kind = Op::MAX; op.in_buf = in_buf; op.out_buf = ob; op.C = m.C; op.log2S = log2S;
-    T.ops.push_back(op);
-    return ob;
-  }
-
   // fully connected stack on a [NB,1,C] feature (utils/tf_util.py:314-351)
   int fc_stack(Tower& T, int in_buf, ChanMap m, const std::vector<std::string>& scopes, const std::vector<int>& widths,
                bool last_relu, int first_in_cstride = 0) {
@@ -534,11 +526,11 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       PoolParams p;
       memset(&p, 0, sizeof(p));
       p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf];
-      p.npoints_ptr = rc.npoints_ptr; p.point_index = ext_in ? rc.point_index : nullptr;
+      p.npoints_ptr = rc.npoints_ptr;
       p.npoints = rc.NB;
       p.in_cstride = T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
       p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
-      p.C = op.C; p.log2S = op.log2S; p.k = op.k;
+      p.C = op.C; p.log2S = op.log2S;
       prof_begin(NESTI_PROF_POOL, rc.stream);
       const int rcp = launch_maxpool2(p, dtype, rc.stream);
       prof_end(NESTI_PROF_POOL, rc.stream);

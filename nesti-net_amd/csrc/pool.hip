@@ -1,5 +1,6 @@
-// Memory-bound helper kernels of the CNN towers: 3-D average / max pooling on
-// channels-last activations, the gating softmax + arg-max + routing, and the final scatter.
+// Memory-bound helper kernels of the CNN towers: 2^3 max pooling on channels-last activations (the
+// average pool and most max pools are fused into conv epilogues, conv.hip), the gating softmax +
+// arg-max + routing, and the final scatter.
 #include "kernels.h"
 
 namespace nesti {
@@ -37,57 +38,6 @@ template <int DT> struct Vec16_16 {
 };
 template <> struct Vec16<NESTI_BF16> : Vec16_16<NESTI_BF16> {};
 template <> struct Vec16<NESTI_F16> : Vec16_16<NESTI_F16> {};
-
-// tf.nn.avg_pool3d k^3 stride 1 SAME (utils/tf_util.py:450-454): mean over the taps inside the
-// volume; window offsets follow TF SAME (low pad = (k-1)/2).
-template <int DT>
-__global__ __launch_bounds__(kThreads) void avgpool_kernel(const PoolParams p) {
-  using V = Vec16<DT>;
-  constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
-  int npts = p.npoints;
-  if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
-  const int log2S = p.log2S, S = 1 << log2S, log2V = 3 * log2S;
-  const int vecs = p.C / V::N;
-  const long long total = ((long long)npts << log2V) * vecs;
-  const int lo = (p.k - 1) / 2;
-  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
-  unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
-  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
-    const int cv = (int)(i % vecs);
-    const long long row = i / vecs;
-    const long long pt = row >> log2V;
-    const int vox = (int)(row & ((1 << log2V) - 1));
-    const int z = vox >> (2 * log2S), y = (vox >> log2S) & (S - 1), x = vox & (S - 1);
-    const long long spt = p.point_index ? (long long)p.point_index[pt] : pt;
-    float acc[V::N];
-#pragma unroll
-    for (int e = 0; e < V::N; ++e) acc[e] = 0.f;
-    int cnt = 0;
-    for (int a = 0; a < p.k; ++a) {
-      const int zz = z + a - lo;
-      if ((unsigned)zz >= (unsigned)S) continue;
-      for (int b = 0; b < p.k; ++b) {
-        const int yy = y + b - lo;
-        if ((unsigned)yy >= (unsigned)S) continue;
-        for (int c = 0; c < p.k; ++c) {
-          const int xx = x + c - lo;
-          if ((unsigned)xx >= (unsigned)S) continue;
-          const long long srow = (spt << log2V) + (((zz << log2S) + yy) << log2S) + xx;
-          const uint4 v = *reinterpret_cast<const uint4*>(in_b + (srow * p.in_cstride + p.in_coff) * kEsz + cv * 16);
-          float f[V::N];
-          V::unpack(v, f);
-#pragma unroll
-          for (int e = 0; e < V::N; ++e) acc[e] += f[e];
-          ++cnt;
-        }
-      }
-    }
-    const float cf = (float)cnt;
-#pragma unroll
-    for (int e = 0; e < V::N; ++e) acc[e] = acc[e] / cf;
-    *reinterpret_cast<uint4*>(out_b + (row * p.out_cstride + p.out_coff) * kEsz + cv * 16) = V::pack(acc);
-  }
-}
 
 // tf.nn.max_pool3d 2^3 stride 2 SAME on an even volume (utils/tf_util.py:424-428)
 template <int DT>
@@ -179,19 +129,6 @@ int grid_for(long long work) {
 }
 
 }  // namespace
-
-int launch_avgpool(const PoolParams& p, int dtype, hipStream_t stream) {
-  if (p.npoints <= 0) return 0;
-  const int n = (dtype == NESTI_F32) ? 4 : 8;
-  if (p.C % n) NESTI_FAIL("avgpool: C must be a multiple of the 16-byte vector");
-  const long long work = ((long long)p.npoints << (3 * p.log2S)) * (p.C / n);
-  dim3 grid(grid_for(work)), block(kThreads);
-  if (dtype == NESTI_F32) hipLaunchKernelGGL(avgpool_kernel<NESTI_F32>, grid, block, 0, stream, p);
-  else if (dtype == NESTI_BF16) hipLaunchKernelGGL(avgpool_kernel<NESTI_BF16>, grid, block, 0, stream, p);
-  else hipLaunchKernelGGL(avgpool_kernel<NESTI_F16>, grid, block, 0, stream, p);
-  NESTI_CHECK_HIP(hipGetLastError());
-  return 0;
-}
 
 int launch_maxpool2(const PoolParams& p, int dtype, hipStream_t stream) {
   if (p.npoints <= 0) return 0;
