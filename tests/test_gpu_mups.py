@@ -111,3 +111,23 @@ def test_mups_properties_full_size(gpu_device):
         pts2[b, P:P + m] = pts[b, P:P + m][perm]
     b2 = mups_forward(cfg, torch.as_tensor(pts2, device=dev), torch.as_tensor(n_eff, device=dev))
     assert (a - b2).abs().max().item() < 1e-5
+
+
+def test_mups_other_patch_sizes_and_scale_counts(gpu_device):
+    """P = 64 points per scale, 2 and 4 scales (the kernel is generic in S <= 4 and P)."""
+    from nesti_net_amd.config import NestiConfig
+    from oracle import mups_ref
+    rng = np.random.RandomState(11)
+    for S, P in ((2, 64), (4, 96)):
+        cfg = NestiConfig(patch_radius=[0.01 * (i + 1) for i in range(S)], num_point=P, n_experts=1,
+                          expert_dict={0: list(range(S))})
+        B = 5
+        n_eff = rng.randint(1, P + 1, size=(B, S)).astype(np.int32)
+        n_eff[0, :] = P
+        pts = (rng.normal(size=(B, S * P, 3)) * 0.3).astype(np.float32)
+        mask = (np.arange(P)[None, None, :] < n_eff[:, :, None]).reshape(B, S * P)
+        pts *= mask[..., None]
+        got = _run(cfg, pts, n_eff, gpu_device)
+        ref = mups_ref.mups_assemble(pts, n_eff, S)
+        assert got.shape == (B, 8, 8, 8, 20 * S)
+        assert np.abs(got - ref).max() < TOL_F32, (S, P)

@@ -233,3 +233,28 @@ def test_multi_scale_ablation_matches_oracle(gpu_device):
     c = _cos(normals.cpu().numpy(), ref)
     print("ms_norm_est min cosine (f32):", c.min())
     assert np.all(1 - c < COS_TOL_F32)
+
+
+def test_other_expert_layouts_match_oracle(gpu_device):
+    """The graph builder follows expert_dict / n_experts generically (models/experts_n_est.py:83-103): 4 experts
+    {0:[0], 1:[1,2], 2:[2], 3:[0,1,2]} -- a 2-scale expert gets 128/2 = 64 first-block filters."""
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from oracle import mups_ref, net_ref
+    ed = {0: [0], 1: [1, 2], 2: [2], 3: [0, 1, 2]}
+    cfg = NestiConfig(n_experts=4, expert_dict=ed)
+    W = weights.synthetic_weights(cfg)
+    assert W["inception1Expert_1_conv1/weights"].shape == (1, 1, 1, 40, 64)
+    assert W["fc4noise/weights"].shape == (128, 4)
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid20k" in p][0])
+    pts, n_eff = g["points"][:5], g["n_eff"][:5]
+    net = NestiNet(cfg, W, dtype="f32", device=gpu_device, max_batch=5)
+    mups = net.mups(torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device))
+    n_est = net.experts(mups, None).cpu().numpy()
+    probs, expert = net.gate(mups)
+    ref = net_ref.moe_forward(mups_ref.mups_assemble(pts, n_eff, 3), W, expert_dict=ed, dtype=torch.float64)
+    assert n_est.shape == (4, 5, 3)
+    assert np.all(1 - _cos(n_est, ref["n_est"].numpy()) < COS_TOL_F32)
+    assert np.abs(probs.cpu().numpy() - ref["probs"].numpy()).max() < PROB_TOL_F32
+    assert np.array_equal(expert.cpu().numpy(), ref["expert"].numpy())
