@@ -30,6 +30,20 @@ __global__ __launch_bounds__(512) void k(const uint4* in, float* out, int iters,
                      : "=&s"(keep) : "v"(src + piece * 1024 + lane * 16), "s"(lds0 + 65536 + piece * 1024) : "memory");
       }
     }
+    if ((MODE == 4 || MODE == 5) && (it & 3) == 0) {   // 1x1-layer pattern: 80 KB (A 64 + B 16) per 4 K-steps, L2-resident source
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(in) + (((it >> 2) & 1) * 65536) + ((blockIdx.x & 7) * 16384);
+      for (int q = 0; q < 10; ++q) {
+        const int piece = wave * 10 + q;
+        if (MODE == 4) {
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(src + (piece & 63) * 1024 + lane * 16), "s"(lds0 + 49152 + piece * 1024) : "memory");
+        } else {
+          const uint4 v = *reinterpret_cast<const uint4*>(src + (piece & 63) * 1024 + lane * 16);
+          *reinterpret_cast<uint4*>(smem + 49152 + piece * 1024 + lane * 16) = v;
+        }
+      }
+    }
     if (MODE >= 1) {   // fragment reads from LDS each K-step, like the conv kernel (prefetch distance 1 handled by compiler)
       const int base = ((it * 6) & 127) * 64 + lane;
       for (int i = 0; i < 2; ++i) a[i] = l[base + i * 64];
@@ -40,8 +54,12 @@ __global__ __launch_bounds__(512) void k(const uint4* in, float* out, int iters,
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni)
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
-    if (MODE >= 2 && (it & 7) == 7) {
+    if ((MODE == 2 || MODE == 3) && (it & 7) == 7) {
       if (MODE >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (MODE >= 4 && (it & 3) == 3) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
   }
@@ -54,20 +72,23 @@ __global__ __launch_bounds__(512) void k(const uint4* in, float* out, int iters,
 
 int main() {
   uint4* in; float* out; long long* cyc;
-  hipMalloc(&in, 8192 * 16); hipMemset(in, 0x3c, 8192 * 16);
-  const char* names[4] = {"register operands", "LDS frag reads", "+ barrier / 8 K-steps", "+ 32 KB LDS-DMA / 8 K-steps"};
+  hipMalloc(&in, 1 << 20); hipMemset(in, 0x3c, 1 << 20);
+  const char* names[6] = {"register operands", "LDS frag reads", "+ barrier / 8 K-steps", "+ 32 KB LDS-DMA / 8 K-steps",
+                          "1x1 pattern: 80 KB LDS-DMA + barrier / 4 K-steps", "1x1 pattern: 80 KB via VGPR + ds_write / 4 K-steps"};
   hipMalloc(&out, 256 * 512 * 4 * 8); hipMalloc(&cyc, 8);
   const int iters = 4000;
-  for (int mode = 0; mode < 4; ++mode)
+  for (int mode = 0; mode < 6; ++mode)
     for (int threads : {256, 512}) {
-      if (mode == 3 && threads != 512) continue;
+      if (mode >= 3 && threads != 512) continue;
       for (int rep = 0; rep < 2; ++rep) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
         if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(256), dim3(threads), 131072, 0, in, out, iters, cyc);
         else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 131072, 0, in, out, iters, cyc);
         else if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(256), dim3(threads), 131072, 0, in, out, iters, cyc);
-        else hipLaunchKernelGGL(k<3>, dim3(256), dim3(threads), 131072, 0, in, out, iters, cyc);
+        else if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(256), dim3(threads), 131072, 0, in, out, iters, cyc);
+        else if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(256), dim3(threads), 131072, 0, in, out, iters, cyc);
+        else hipLaunchKernelGGL(k<5>, dim3(256), dim3(threads), 131072, 0, in, out, iters, cyc);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
