@@ -641,6 +641,7 @@ int nesti_gmm_grid(int n, double variance, float* w, float* mu, float* sigma) {
 
 int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev, const int32_t* n_eff_dev, int B,
                        void* out_dev, int out_dtype, int out_cstride, void* stream) {
+  if (B <= 0) return 0;   // empty batch: nothing to do
   if (!cfg || !points_dev || !n_eff_dev || !out_dev) NESTI_FAIL("nesti_mups_forward: null argument");
   prof_begin(NESTI_PROF_MUPS, (hipStream_t)stream);
   const int rc = launch_mups(cfg, points_dev, n_eff_dev, B, out_dev, out_dtype, out_cstride, (hipStream_t)stream);
@@ -698,6 +699,7 @@ int nesti_model_mups_cstride(const nesti_model_t* m) { return m ? m->graph.mups_
 
 int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void* ws_dev, size_t ws_bytes,
                        float* probs_out_dev, int32_t* expert_out_dev, void* stream) {
+  if (B <= 0) return 0;   // empty batch: nothing to do
   if (!m || !mups_dev || !ws_dev) NESTI_FAIL("nesti_gate_forward: null argument");
   if (m->graph.cfg.arch != NESTI_ARCH_EXPERTS) NESTI_FAIL("nesti_gate_forward: this model has no gating net");
   if (B <= 0) return 0;
@@ -711,6 +713,7 @@ int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void
 
 int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const int32_t* expert_dev, int B, void* ws_dev,
                           size_t ws_bytes, float* normals_out_dev, void* stream) {
+  if (B <= 0) return 0;   // empty batch: nothing to do
   if (!m || !mups_dev || !ws_dev || !normals_out_dev) NESTI_FAIL("nesti_experts_forward: null argument");
   if (B <= 0) return 0;
   const WsLayout L = ws_layout(m, B);
@@ -729,6 +732,7 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
 
 int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B, void* ws_dev,
                   size_t ws_bytes, float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, void* stream) {
+  if (B <= 0) return 0;   // empty batch: nothing to do
   if (!m || !points_dev || !n_eff_dev || !ws_dev || !normals_out_dev) NESTI_FAIL("nesti_forward: null argument");
   if (B <= 0) return 0;
   const WsLayout L = ws_layout(m, B);

@@ -258,3 +258,12 @@ def test_other_expert_layouts_match_oracle(gpu_device):
     assert np.all(1 - _cos(n_est, ref["n_est"].numpy()) < COS_TOL_F32)
     assert np.abs(probs.cpu().numpy() - ref["probs"].numpy()).max() < PROB_TOL_F32
     assert np.array_equal(expert.cpu().numpy(), ref["expert"].numpy())
+
+
+def test_empty_batch_is_a_no_op(setup, net_f32, gpu_device):
+    cfg, W, pts, n_eff = setup
+    p = torch.zeros((0, 1536, 3), dtype=torch.float32, device=gpu_device)
+    n = torch.zeros((0, 3), dtype=torch.int32, device=gpu_device)
+    normals, expert, probs = net_f32(p, n)
+    assert normals.shape == (0, 3) and expert.shape == (0,) and probs.shape == (0, 7)
+    assert net_f32.mups(p, n).shape[0] == 0
