@@ -65,6 +65,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64; it must be the HIP runtime of the process, so import torch BEFORE
+    # dlopen()ing our library (otherwise /opt/rocm's copy is loaded first and the two runtimes disagree about devices)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise NestiError(
             "libnesti_hip.so not found at %s -- build it first: "
