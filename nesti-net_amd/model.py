@@ -93,10 +93,13 @@ class NestiNet:
         self.reserve(max_batch)
 
     def __del__(self):
-        h = getattr(self, "_handle", None)
-        if h is not None and h.value:
-            self.lib.nesti_model_destroy(h)
-            self._handle = ctypes.c_void_p()
+        try:
+            h = getattr(self, "_handle", None)
+            if h is not None and h.value:
+                self.lib.nesti_model_destroy(h)
+                h.value = None
+        except Exception:      # interpreter shutdown: modules may already be torn down
+            pass
 
     # -- workspace -------------------------------------------------------------------------
     def reserve(self, batch):
