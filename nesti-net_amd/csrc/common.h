@@ -30,11 +30,12 @@ static inline size_t dtype_size(int dt) { return dt == NESTI_F32 ? 4 : 2; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- element conversion (device) ------------------------------------------
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even, quiet NaN): no branches per element.
+typedef __attribute__((ext_vector_type(2))) float nesti_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 nesti_bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 nesti_f16x2;
 __device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                            // RNE
-  return (uint16_t)(u >> 16);
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
 }
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
@@ -58,11 +59,17 @@ template <> struct Elem<NESTI_BF16> {
   using T = uint16_t;
   static __device__ __forceinline__ T from_f32(float f) { return f32_to_bf16_bits(f); }
   static __device__ __forceinline__ float to_f32(T v) { return bf16_bits_to_f32(v); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {   // two elements in one dword, lo at the lower address
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((nesti_f32x2){lo, hi}, nesti_bf16x2));
+  }
 };
 template <> struct Elem<NESTI_F16> {
   using T = uint16_t;
   static __device__ __forceinline__ T from_f32(float f) { return f32_to_f16_bits(f); }
   static __device__ __forceinline__ float to_f32(T v) { return f16_bits_to_f32(v); }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((nesti_f32x2){lo, hi}, nesti_f16x2));
+  }
 };
 
 // host-side conversions used by the weight repacker

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   const int n_local = second ? n_tile - p.split_tile : n_tile;
   const int out_col0 = (second ? p.out_coff2 : p.out_coff) + n_local * TN;
   const float* bias = p.bias + n_tile * TN;
+  const float act_floor = p.relu ? 0.f : -INFINITY;      // ReLU as one v_max
 
   if (KPIPE && second && p.pool_k > 1) {
     // avg_pool3d(k, SAME, stride 1) of the pre-activation: per 64-column half the fp32 accumulators go
@@ -279,18 +280,23 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
         const int line = item >> 4, cg = item & 15;
         const int y = line & (S_ - 1), z = (line >> log2S_) & (S_ - 1);
         const int row0 = line << log2S_;
-        float4 sum[S_];
+        // separable box sum: add the K^2 neighbouring x-lines first, then one x window over the column sums
+        float4 colsum[S_];
 #pragma unroll
-        for (int x = 0; x < S_; ++x) sum[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int x = 0; x < S_; ++x) colsum[x] = make_float4(0.f, 0.f, 0.f, 0.f);
         int nz = 0, ny = 0;
 #pragma unroll
         for (int a = 0; a < K_; ++a) nz += ((unsigned)(z + a - lo) < (unsigned)S_) ? 1 : 0;
 #pragma unroll
         for (int b = 0; b < K_; ++b) ny += ((unsigned)(y + b - lo) < (unsigned)S_) ? 1 : 0;
+        // the axis whose neighbours sit in one lane's accumulators was already summed in registers (pool_half):
+        // S = 8 -> y, S = 4 -> z; only the other one is walked here
+        constexpr int a_lo = (S_ == 4) ? lo : 0, a_hi = (S_ == 4) ? lo + 1 : K_;
+        constexpr int b_lo = (S_ == 8) ? lo : 0, b_hi = (S_ == 8) ? lo + 1 : K_;
 #pragma unroll 1   // keep at most K lines x S loads in flight: full unrolling spills
-        for (int a = 0; a < K_; ++a) {
+        for (int a = a_lo; a < a_hi; ++a) {
 #pragma unroll
-          for (int b = 0; b < K_; ++b) {
+          for (int b = b_lo; b < b_hi; ++b) {
             const bool ok = ((unsigned)(z + a - lo) < (unsigned)S_) & ((unsigned)(y + b - lo) < (unsigned)S_);
             const int nrow0 = row0 + (((a - lo) * S_ + (b - lo)) << log2S_);
             const unsigned char* base = ok ? smem + nrow0 * kPoolStride + cg * 16 : zero16;
@@ -299,14 +305,17 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
             for (int x = 0; x < S_; ++x) v[x] = *reinterpret_cast<const float4*>(base + x * stride);
 #pragma unroll
-            for (int x = 0; x < S_; ++x) {
+            for (int x = 0; x < S_; ++x) { colsum[x].x += v[x].x; colsum[x].y += v[x].y; colsum[x].z += v[x].z; colsum[x].w += v[x].w; }
+          }
+        }
+        float4 sum[S_];
 #pragma unroll
-              for (int c = 0; c < K_; ++c) {
-                constexpr int dummy = 0; (void)dummy;
-                const int xx = x + c - lo;
-                if (xx >= 0 && xx < S_) { sum[x].x += v[xx].x; sum[x].y += v[xx].y; sum[x].z += v[xx].z; sum[x].w += v[xx].w; }
-              }
-            }
+        for (int x = 0; x < S_; ++x) {
+          sum[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int c = 0; c < K_; ++c) {
+            const int xx = x + c - lo;
+            if (xx >= 0 && xx < S_) { sum[x].x += colsum[xx].x; sum[x].y += colsum[xx].y; sum[x].z += colsum[xx].z; sum[x].w += colsum[xx].w; }
           }
         }
         const float4 bb = *reinterpret_cast<const float4*>(bias + nh * 64 + cg * 4);
@@ -316,11 +325,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
           for (int c = 0; c < K_; ++c) nx += (x + c - lo >= 0 && x + c - lo < S_) ? 1 : 0;
           const float inv = 1.0f / (float)(nz * ny * nx);      // taps inside the volume (utils/tf_util.py:450-454)
-          float o[4] = {sum[x].x * inv + bb.x, sum[x].y * inv + bb.y, sum[x].z * inv + bb.z, sum[x].w * inv + bb.w};
-          if (p.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-          }
+          const float o[4] = {fmaxf(sum[x].x * inv + bb.x, act_floor), fmaxf(sum[x].y * inv + bb.y, act_floor),
+                              fmaxf(sum[x].z * inv + bb.z, act_floor), fmaxf(sum[x].w * inv + bb.w, act_floor)};
           const long long gr = r0 + row0 + x;
           if (gr < total_rows) {
             unsigned char* dst = out_b + (gr * p.out_cstride + out_col0 + nh * 64 + cg * 4) * out_esz;
@@ -328,38 +334,61 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
               *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
               using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
-              const uint32_t w0 = (uint32_t)E::from_f32(o[0]) | ((uint32_t)E::from_f32(o[1]) << 16);
-              const uint32_t w1 = (uint32_t)E::from_f32(o[2]) | ((uint32_t)E::from_f32(o[3]) << 16);
-              *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
+              *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(o[0], o[1]), E::pack2(o[2], o[3]));
             }
           }
         }
       }
     };
-    // one call per 64-column half with a compile-time index: runtime-indexed register arrays go to scratch
-    auto pool_half = [&](auto NH) __attribute__((always_inline)) {
-      constexpr int nh = decltype(NH)::value;
+    // one call per 64-column half with a compile-time index: runtime-indexed register arrays go to scratch.
+    // A lane's 32 accumulators of one column cover row bits {0,1} (r&3), {3,4} (r>>2) and 5 (mi): at 8^3 that is
+    // the whole y axis, at 4^3 the whole z axis.  That axis of the box sum is taken here on registers (K-1 adds
+    // per value, no LDS), which divides the LDS line reads of pool_lines by K.
+    auto pool_half = [&](auto NH, auto SS, auto KK) __attribute__((always_inline)) {
+      constexpr int nh = decltype(NH)::value, S_ = decltype(SS)::value, K_ = decltype(KK)::value;
+      constexpr int lo = (K_ - 1) / 2;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int n2 = 0; n2 < 2; ++n2) {
+        const int ni = nh * 2 + n2;
+        const int col = n2 * 32 + (lane & 31);
 #pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) {
-          const int ni = nh * 2 + n2;
-          const int col = n2 * 32 + (lane & 31);
+        for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
+            float v = 0.f;
+            if constexpr (S_ == 8) {            // y = (r>>2) + 4*mi
+              const int y = (r >> 2) + 4 * mi;
+#pragma unroll
+              for (int b = 0; b < K_; ++b) {
+                const int yy = y + b - lo;
+                if (yy >= 0 && yy < 8) v += acc[yy >> 2][ni][((yy & 3) << 2) | (r & 3)];
+              }
+            } else if constexpr (S_ == 4) {     // z = (r>>3) + 2*mi
+              const int z = (r >> 3) + 2 * mi;
+#pragma unroll
+              for (int a = 0; a < K_; ++a) {
+                const int zz = z + a - lo;
+                if (zz >= 0 && zz < 4) v += acc[zz >> 1][ni][((zz & 1) << 3) | (r & 7)];
+              }
+            } else {
+              v = acc[mi][ni][r];
+            }
             const int row = wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = acc[mi][ni][r];
+            *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = v;
           }
-        }
+      }
       __syncthreads();
-      if (log2S == 3 && p.pool_k == 3) pool_lines(std::integral_constant<int, 8>{}, std::integral_constant<int, 3>{}, nh);
-      else if (log2S == 2 && p.pool_k == 2) pool_lines(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, nh);
-      else if (log2S == 2 && p.pool_k == 3) pool_lines(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{}, nh);
-      else if (log2S == 1 && p.pool_k == 2) pool_lines(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, nh);
+      pool_lines(SS, KK, nh);
       __syncthreads();
     };
-    pool_half(std::integral_constant<int, 0>{});
-    if constexpr (TN == 128) pool_half(std::integral_constant<int, 1>{});
+    auto pool_tile = [&](auto SS, auto KK) __attribute__((always_inline)) {
+      pool_half(std::integral_constant<int, 0>{}, SS, KK);
+      if constexpr (TN == 128) pool_half(std::integral_constant<int, 1>{}, SS, KK);
+    };
+    if (log2S == 3 && p.pool_k == 3) pool_tile(std::integral_constant<int, 8>{}, std::integral_constant<int, 3>{});
+    else if (log2S == 2 && p.pool_k == 2) pool_tile(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+    else if (log2S == 2 && p.pool_k == 3) pool_tile(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
+    else if (log2S == 1 && p.pool_k == 2) pool_tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
     return;
   }
 
@@ -374,9 +403,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
         *reinterpret_cast<float4*>(dst) = v;
       } else {
         using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
-        const uint32_t w0 = (uint32_t)E::from_f32(v.x) | ((uint32_t)E::from_f32(v.y) << 16);
-        const uint32_t w1 = (uint32_t)E::from_f32(v.z) | ((uint32_t)E::from_f32(v.w) << 16);
-        *reinterpret_cast<uint2*>(dst) = make_uint2(w0, w1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v.x, v.y), E::pack2(v.z, v.w));
       }
     };
     auto mp_half = [&](auto NH) __attribute__((always_inline)) {
@@ -391,9 +418,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            float v = acc[mi][ni][r] + bv;
-            if (p.relu) v = fmaxf(v, 0.f);
-            *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = v;
+            *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = fmaxf(acc[mi][ni][r] + bv, act_floor);
           }
         }
       __syncthreads();
@@ -433,11 +458,9 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
     return;
   }
 
-  // plain epilogue: bias + ReLU, transpose through a wave-private LDS scratch, 16-B stores
-  unsigned char* scratch = smem + wave * 8192;
-  const int seg = 64 * out_esz;                 // bytes of one 64-channel row segment
-  const int lanes_per_row = seg >> 4;           // 8 or 16
-  const int rows_per_iter = 64 / lanes_per_row; // 8 or 4
+  // plain epilogue: bias + ReLU in fp32, transpose 32 x 64 blocks through a wave-private fp32 LDS scratch, then
+  // convert on the way out (one lane = 16 output bytes) -- no per-element branches, no sub-dword LDS writes
+  unsigned char* scratch = smem + wave * (32 * kPoolStride);
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -450,19 +473,29 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-          float v = acc[mi][ni][r] + bv;
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (out_esz == 4) reinterpret_cast<float*>(scratch)[row * 64 + col] = v;
-          else reinterpret_cast<uint16_t*>(scratch)[row * 64 + col] = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>::from_f32(v);
+          *reinterpret_cast<float*>(scratch + row * kPoolStride + col * 4) = fmaxf(acc[mi][ni][r] + bv, act_floor);
         }
       }
-      for (int it = 0; it < 32 / rows_per_iter; ++it) {
-        const int row = it * rows_per_iter + lane / lanes_per_row;
-        const int cpos = lane % lanes_per_row;
-        const uint4 v = *reinterpret_cast<const uint4*>(scratch + row * seg + cpos * 16);
-        const long long gr = r0 + wave * 64 + mi * 32 + row;
-        if (gr < total_rows)
-          *reinterpret_cast<uint4*>(out_b + (gr * p.out_cstride + out_col0 + nh * 64) * out_esz + cpos * 16) = v;
+      const long long gr0 = r0 + wave * 64 + mi * 32;
+      if (out_esz == 4) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {                     // 16 lanes x 16 B = one 64-float row segment
+          const int row = it * 4 + (lane >> 4), cpos = lane & 15;
+          const uint4 v = *reinterpret_cast<const uint4*>(scratch + row * kPoolStride + cpos * 16);
+          if (gr0 + row < total_rows)
+            *reinterpret_cast<uint4*>(out_b + ((gr0 + row) * p.out_cstride + out_col0 + nh * 64) * 4 + cpos * 16) = v;
+        }
+      } else {
+        using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                     // 8 lanes x 16 B = one 64-element row segment
+          const int row = it * 8 + (lane >> 3), cpos = lane & 7;
+          const float4 f0 = *reinterpret_cast<const float4*>(scratch + row * kPoolStride + cpos * 32);
+          const float4 f1 = *reinterpret_cast<const float4*>(scratch + row * kPoolStride + cpos * 32 + 16);
+          const uint4 v = make_uint4(E::pack2(f0.x, f0.y), E::pack2(f0.z, f0.w), E::pack2(f1.x, f1.y), E::pack2(f1.z, f1.w));
+          if (gr0 + row < total_rows)
+            *reinterpret_cast<uint4*>(out_b + ((gr0 + row) * p.out_cstride + out_col0 + nh * 64) * 2 + cpos * 16) = v;
+        }
       }
     }
   }
