@@ -38,7 +38,10 @@ enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2 };
 enum {
   NESTI_ARCH_EXPERTS = 0, /* models/experts_n_est.py:40-108  (MoE, the hot path)    */
   NESTI_ARCH_SINGLE = 1,  /* models/ss_norm_est.py:35-92     (BASELINE config 0)    */
-  NESTI_ARCH_MULTI = 2    /* models/ms_norm_est.py:45-140    (multi-scale ablation) */
+  NESTI_ARCH_MULTI = 2,   /* models/ms_norm_est.py:45-140    (multi-scale ablation) */
+  NESTI_ARCH_SWITCH = 3   /* models/ms_sw_n_est.py:41-89     (noise-switched two-scale ablation):
+                           * 2 scales; gate = noise_est_net on scale 1, tower 0 = 'small' (scale 0),
+                           * tower 1 = 'large' (scale 1); n_experts / expert_scale_* are ignored      */
 };
 
 /* Hyper-parameters the reference reads from parameters.p / gmm.p
@@ -140,7 +143,9 @@ int nesti_model_mups_cstride(const nesti_model_t* m); /* channel stride of the i
 /* scale_manager_net + arg-max (models/experts_n_est.py:155-179,
  * test_n_est_w_experts.py:150): mups_dev is [B,R^3,cstride] in the model dtype.
  * probs_out_dev [B,E] f32 (row-major, i.e. the transpose done at :151),
- * expert_out_dev [B] int32 (first index on ties, like np.argmax). */
+ * expert_out_dev [B] int32 (first index on ties, like np.argmax).
+ * NESTI_ARCH_SWITCH: probs_out_dev is [B,1] = noise_est (models/ms_sw_n_est.py:75) and
+ * expert_out_dev[b] = noise_est < 0.015 ? 0 (small) : 1 (large) (:80-82). */
 int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void* ws_dev,
                        size_t ws_bytes, float* probs_out_dev, int32_t* expert_out_dev,
                        void* stream);
@@ -158,7 +163,9 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
  * (test_n_est_w_experts.py:142-152) with top-1 routing:
  *   points_dev [B,S*P,3] f32, n_eff_dev [B,S] int32 ->
  *   normals_out_dev [B,3] f32, expert_out_dev [B] int32, probs_out_dev [B,E] f32.
- * For NESTI_ARCH_SINGLE / NESTI_ARCH_MULTI only normals are produced (expert/probs may be NULL). */
+ * For NESTI_ARCH_SINGLE / NESTI_ARCH_MULTI only normals are produced (expert/probs may be NULL).
+ * For NESTI_ARCH_SWITCH (one sess.run of test_n_est_w_switching.py:136) probs_out_dev is [B,1] =
+ * noise_est and expert_out_dev the tower chosen by the 0.015 threshold. */
 int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev,
                   int B, void* ws_dev, size_t ws_bytes, float* normals_out_dev,
                   int32_t* expert_out_dev, float* probs_out_dev, void* stream);

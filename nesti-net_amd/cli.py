@@ -16,7 +16,7 @@ import torch
 
 from . import textio
 from . import weights as wts
-from .config import ARCH_EXPERTS, ARCH_MULTI, ARCH_SINGLE, NestiConfig
+from .config import ARCH_EXPERTS, ARCH_MULTI, ARCH_SINGLE, ARCH_SWITCH, NestiConfig
 from .pipeline import NormalEstimator
 from .provider import PointcloudPatchDataset
 
@@ -40,9 +40,10 @@ def build_parser():
 
 def main(argv=None):
     FLAGS = build_parser().parse_args(argv)
-    archs = {"experts_n_est": ARCH_EXPERTS, "ss_norm_est": ARCH_SINGLE, "ms_norm_est": ARCH_MULTI}
+    archs = {"experts_n_est": ARCH_EXPERTS, "ss_norm_est": ARCH_SINGLE, "ms_norm_est": ARCH_MULTI,
+             "ms_sw_n_est": ARCH_SWITCH}      # test_n_est_w_experts.py / test_n_est.py / test_n_est_w_switching.py
     if FLAGS.model not in archs:
-        raise SystemExit("--model must be one of %s (ms_sw_n_est, the switching ablation, is out of scope)" % sorted(archs))
+        raise SystemExit("--model must be one of %s" % sorted(archs))
     arch = archs[FLAGS.model]
     results_path = FLAGS.results_path
     base = os.getcwd()
@@ -67,11 +68,7 @@ def main(argv=None):
         printout("Loading model %s" % os.path.join(results_path, "model.ckpt"))
         cfg, W = tf_ckpt.load_reference_model(results_path)
     elif FLAGS.synthetic_weights:
-        cfg = NestiConfig()
-        if arch == ARCH_SINGLE:      # test_n_est.py drives the single-tower ablations the same way (:59-166)
-            cfg = NestiConfig(patch_radius=[0.05], n_experts=1, expert_dict={0: [0]}, arch=arch)
-        elif arch == ARCH_MULTI:
-            cfg = NestiConfig(n_experts=1, expert_dict={0: [0, 1, 2]}, arch=arch)
+        cfg = NestiConfig.for_model(FLAGS.model)
         printout("No %s: using synthetic weights (seed %d)" % (model_file, wts.WEIGHT_SEED))
         W = wts.synthetic_weights(cfg)
     else:
@@ -91,8 +88,8 @@ def main(argv=None):
         # byte-identical to the reference's np.savetxt calls (test_n_est_w_experts.py:182-188), ~6x faster
         textio.write_f32(os.path.join(output_dir, name + ".normals"), normals.cpu().numpy())
         printout("saved normals for " + name)
-        if expert is None:           # single-tower ablations write .normals only (test_n_est.py:118)
-            continue
+        if expert is None or arch == ARCH_SWITCH:   # the ablation drivers write .normals only (test_n_est.py:118,
+            continue                                 # test_n_est_w_switching.py:158)
         textio.write_i32(os.path.join(output_dir, name + ".experts"), expert.cpu().numpy())
         textio.write_f32(os.path.join(output_dir, name + ".experts_probs"), probs.cpu().numpy())
         printout("saved experts for " + name)

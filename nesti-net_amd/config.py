@@ -8,7 +8,8 @@ from typing import Dict, List
 MAX_SCALES = 4
 MAX_EXPERTS = 8
 DTYPES = {"f32": 0, "bf16": 1, "f16": 2}
-ARCH_EXPERTS, ARCH_SINGLE, ARCH_MULTI = 0, 1, 2
+ARCH_EXPERTS, ARCH_SINGLE, ARCH_MULTI, ARCH_SWITCH = 0, 1, 2, 3
+SWITCH_NOISE_THRESHOLD = 0.015   # models/ms_sw_n_est.py:80
 
 # train_n_est_w_experts.py:62 (JSON-in-JSON there; plain dict here)
 TRAINED_EXPERT_DICT = {0: [0], 1: [0], 2: [1], 3: [1], 4: [2], 5: [2], 6: [0, 1, 2]}
@@ -40,6 +41,30 @@ class NestiConfig:
     @property
     def n_scales(self):
         return len(self.patch_radius)
+
+    @property
+    def n_towers(self):
+        """Normal-regression towers: E experts, 1 for the single-tower ablations, small+large for ms_sw_n_est."""
+        return {ARCH_EXPERTS: self.n_experts, ARCH_SWITCH: 2}.get(self.arch, 1)
+
+    @property
+    def n_gate_out(self):
+        """Columns of the gate output: E probabilities, the noise estimate for ms_sw_n_est, none otherwise."""
+        return {ARCH_EXPERTS: self.n_experts, ARCH_SWITCH: 1}.get(self.arch, 0)
+
+    @staticmethod
+    def for_model(name):
+        """The command-line defaults of the reference's training scripts for ``--model name``
+        (train_n_est_w_experts.py:20-64, train_n_est.py, train_n_est_w_switching.py:20)."""
+        if name == "experts_n_est":
+            return NestiConfig()
+        if name == "ss_norm_est":
+            return NestiConfig(patch_radius=[0.05], n_experts=1, expert_dict={0: [0]}, arch=ARCH_SINGLE)
+        if name == "ms_norm_est":
+            return NestiConfig(n_experts=1, expert_dict={0: [0, 1, 2]}, arch=ARCH_MULTI)
+        if name == "ms_sw_n_est":
+            return NestiConfig(patch_radius=[0.01, 0.05], n_experts=2, expert_dict={0: [0], 1: [1]}, arch=ARCH_SWITCH)
+        raise ValueError("unknown model %r" % (name,))
 
     def default_expert_dict(self):
         """``models/experts_n_est.py:83-96`` when expert_dict is None."""

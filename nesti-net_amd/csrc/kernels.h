@@ -60,6 +60,11 @@ int launch_maxpool2(const PoolParams& p, int dtype, hipStream_t stream);
 int launch_gate_finish(const float* logits, int lstride, int B, int E, float* probs,
                        int32_t* expert, int32_t* counts /*[E] or NULL*/,
                        int32_t* lists /*[E][B] or NULL*/, hipStream_t stream);
+// ms_sw_n_est's switch (models/ms_sw_n_est.py:80-82): noise = logits[b*lstride]; expert = noise < threshold ? 0 : 1;
+// probs[b] = noise (one column); optional routing lists over the 2 towers.
+int launch_switch_finish(const float* logits, int lstride, int B, float threshold, float* probs,
+                         int32_t* expert, int32_t* counts /*[2] or NULL*/, int32_t* lists /*[2][B] or NULL*/,
+                         hipStream_t stream);
 // build routing lists from a caller-supplied expert assignment
 int launch_route(const int32_t* expert, int B, int E, int32_t* counts, int32_t* lists,
                  hipStream_t stream);

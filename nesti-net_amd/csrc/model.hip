@@ -232,22 +232,16 @@ struct Builder {
     T.n_out = g.cfg.n_experts;
   }
 
-  // The single-tower ablations: ss_norm_est.get_model (models/ss_norm_est.py:35-92; one scale, 4^3 kernels
-  // [3,5], scopes 'inception<L>') and ms_norm_est.get_model (models/ms_norm_est.py:45-140; S scales
-  // concatenated on channels, 4^3 kernels [3,4], scopes 'inception_s<S-1>_l_<L>').  Dropout is the identity at
-  // inference.  The 2^3 x 1536 feature map is flattened voxel-major (tf.reshape) into fc1, which here is an FC
-  // over a flattened view of the same buffer.
-  void build_single() {
-    Tower& T = g.experts[0];
+  // The "ss" tower shared by the ablation models: inception x3 @8^3 [3,5] -> maxpool -> inception x2 @4^3
+  // [3,k1_small] -> maxpool -> flatten 2^3 x 1536 voxel-major (tf.reshape) -> fc 1024/256/128/n_out.  Used by
+  // ss_norm_est.get_model (models/ss_norm_est.py:35-92), ms_norm_est.get_model (models/ms_norm_est.py:45-140) and
+  // the three towers of ms_sw_n_est (models/ms_sw_n_est.py:139-215).  Dropout is the identity at inference.  fc1
+  // is an FC over a flattened view of the pooled buffer.
+  void build_ss_tower(Tower& T, int scale_lo, int scale_cnt, const std::function<std::string(int)>& name,
+                      const std::string& fc_suffix, int n_out, bool last_relu, int k1_small) {
     init_tower(T);
-    const bool multi = g.cfg.arch == NESTI_ARCH_MULTI;
-    const int S = g.cfg.n_scales;
     ChanMap m; m.C = g.mups_cstride;
-    for (int c = 0; c < 20 * S; ++c) m.pos.push_back(c);
-    auto name = [&](int layer) {
-      return multi ? "inception_s" + std::to_string(S - 1) + "_l_" + std::to_string(layer) : "inception" + std::to_string(layer);
-    };
-    const int k1_small = multi ? 4 : 5;
+    for (int c = 0; c < 20 * scale_cnt; ++c) m.pos.push_back(20 * scale_lo + c);
     int b = inception(T, name(1), 0, m, 128, 3, 5, 3, &m);
     b = inception(T, name(2), b, m, 256, 3, 5, 3, &m);
     b = inception(T, name(3), b, m, 256, 3, 5, 3, &m, true);
@@ -256,8 +250,32 @@ struct Builder {
     ChanMap flat; flat.C = 8 * m.C;
     for (int v = 0; v < 8; ++v)
       for (size_t c = 0; c < m.pos.size(); ++c) flat.pos.push_back(v * m.C + m.pos[c]);
-    T.out_buf = fc_stack(T, b, flat, {"fc1", "fc2", "fc3", "fc4"}, {1024, 256, 128, 3}, /*last_relu=*/false, flat.C);
-    T.n_out = 3;
+    T.out_buf = fc_stack(T, b, flat, {"fc1" + fc_suffix, "fc2" + fc_suffix, "fc3" + fc_suffix, "fc4" + fc_suffix},
+                         {1024, 256, 128, n_out}, last_relu, flat.C);
+    T.n_out = n_out;
+  }
+
+  // ss_norm_est (one scale, 4^3 kernels [3,5], scopes 'inception<L>') / ms_norm_est (S scales concatenated on
+  // channels, 4^3 kernels [3,4], scopes 'inception_s<S-1>_l_<L>')
+  void build_single() {
+    const bool multi = g.cfg.arch == NESTI_ARCH_MULTI;
+    const int S = g.cfg.n_scales;
+    auto name = [=](int layer) {
+      return multi ? "inception_s" + std::to_string(S - 1) + "_l_" + std::to_string(layer) : "inception" + std::to_string(layer);
+    };
+    build_ss_tower(g.experts[0], 0, S, name, "", 3, /*last_relu=*/false, multi ? 4 : 5);
+  }
+
+  // ms_sw_n_est.get_model (models/ms_sw_n_est.py:41-89): noise_est_net on the LARGE scale (scale 1) with a ReLU on
+  // its single output (:172), normal_est_net 'small' on scale 0 and 'large' on scale 1 (:77-78); the driver keeps
+  // n_est_small where noise_est < 0.015 (:80-82).  Here: gate = the noise tower, expert 0 = small, expert 1 = large.
+  void build_switch() {
+    auto scoped = [](const std::string& sfx) {
+      return [sfx](int layer) { return "inception" + std::to_string(layer) + sfx; };
+    };
+    build_ss_tower(g.gate, 1, 1, scoped("noise"), "noise", 1, /*last_relu=*/true, 5);
+    build_ss_tower(g.experts[0], 0, 1, scoped("small"), "small", 3, /*last_relu=*/false, 5);
+    build_ss_tower(g.experts[1], 1, 1, scoped("large"), "large", 3, /*last_relu=*/false, 5);
   }
 
   // normal_est_net, 8^3 branch (models/experts_n_est.py:243-291)
@@ -279,13 +297,16 @@ struct Builder {
 };
 
 int build_graph(const nesti_config_t* cfg, Graph* g) {
-  if (cfg->arch != NESTI_ARCH_EXPERTS && cfg->arch != NESTI_ARCH_SINGLE && cfg->arch != NESTI_ARCH_MULTI)
+  if (cfg->arch != NESTI_ARCH_EXPERTS && cfg->arch != NESTI_ARCH_SINGLE && cfg->arch != NESTI_ARCH_MULTI &&
+      cfg->arch != NESTI_ARCH_SWITCH)
     NESTI_FAIL("unknown arch");
+  if (cfg->arch == NESTI_ARCH_SWITCH && cfg->n_scales != 2)
+    NESTI_FAIL("NESTI_ARCH_SWITCH (ms_sw_n_est) takes exactly two scales (models/ms_sw_n_est.py:50)");
   if (cfg->arch == NESTI_ARCH_SINGLE && cfg->n_scales != 1) NESTI_FAIL("NESTI_ARCH_SINGLE (ss_norm_est) takes exactly one scale");
   if (cfg->grid_n != 8) NESTI_FAIL("only the 8^3 Gaussian grid is implemented");
   if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("bad n_scales");
   if (cfg->n_experts < 1 || cfg->n_experts > NESTI_MAX_EXPERTS) NESTI_FAIL("bad n_experts");
-  for (int i = 0; i < cfg->n_experts; ++i) {
+  for (int i = 0; i < cfg->n_experts && cfg->arch == NESTI_ARCH_EXPERTS; ++i) {
     if (cfg->expert_scale_cnt[i] < 1 || cfg->expert_scale_lo[i] < 0 ||
         cfg->expert_scale_lo[i] + cfg->expert_scale_cnt[i] > cfg->n_scales)
       NESTI_FAIL("expert scale range outside [0, n_scales)");
@@ -299,6 +320,14 @@ int build_graph(const nesti_config_t* cfg, Graph* g) {
     g->cfg.n_experts = 1;
     g->experts.assign(1, Tower());
     b.build_single();
+    return 0;
+  }
+  if (cfg->arch == NESTI_ARCH_SWITCH) {
+    g->cfg.n_experts = 2;
+    g->cfg.expert_scale_lo[0] = 0; g->cfg.expert_scale_lo[1] = 1;
+    g->cfg.expert_scale_cnt[0] = g->cfg.expert_scale_cnt[1] = 1;
+    g->experts.assign(2, Tower());
+    b.build_switch();
     return 0;
   }
   b.build_gate();
@@ -570,6 +599,8 @@ int gate_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_
   float* logits = nullptr;
   if (run_tower(rc, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
   const int lstride = m->graph.gate.bufs[m->graph.gate.out_buf].C;
+  if (m->graph.cfg.arch == NESTI_ARCH_SWITCH)   // noise_est < 0.015 -> small, else large (models/ms_sw_n_est.py:80-82)
+    return launch_switch_finish(logits, lstride, B, 0.015f, probs, expert, counts, lists, stream);
   return launch_gate_finish(logits, lstride, B, m->graph.cfg.n_experts, probs, expert, counts, lists, stream);
 }
 
@@ -701,7 +732,8 @@ int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void
                        float* probs_out_dev, int32_t* expert_out_dev, void* stream) {
   if (B <= 0) return 0;   // empty batch: nothing to do
   if (!m || !mups_dev || !ws_dev) NESTI_FAIL("nesti_gate_forward: null argument");
-  if (m->graph.cfg.arch != NESTI_ARCH_EXPERTS) NESTI_FAIL("nesti_gate_forward: this model has no gating net");
+  if (m->graph.cfg.arch != NESTI_ARCH_EXPERTS && m->graph.cfg.arch != NESTI_ARCH_SWITCH)
+    NESTI_FAIL("nesti_gate_forward: this model has no gating net");
   if (B <= 0) return 0;
   const WsLayout L = ws_layout(m, B);
   if (L.total > ws_bytes) NESTI_FAIL("nesti_gate_forward: workspace too small (see nesti_workspace_bytes)");
@@ -744,7 +776,7 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride, st);
   prof_end(NESTI_PROF_MUPS, st);
   if (rcm) return 1;
-  if (m->graph.cfg.arch != NESTI_ARCH_EXPERTS)   // single-tower ablations: the tower's output IS n_pred (test_n_est.py:136-141)
+  if (m->graph.cfg.arch == NESTI_ARCH_SINGLE || m->graph.cfg.arch == NESTI_ARCH_MULTI)   // single-tower ablations: the tower's output IS n_pred (test_n_est.py:136-141)
     return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, nullptr, nullptr, normals_out_dev, st);
   float* probs = probs_out_dev ? probs_out_dev : (float*)(ws + L.probs);
   int32_t* expert = expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert);

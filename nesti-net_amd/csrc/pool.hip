@@ -100,6 +100,22 @@ __global__ void gate_finish_kernel(const float* __restrict__ logits, int lstride
   }
 }
 
+// tf.where(noise_est < 0.015, n_est_small, n_est_large) as a routing decision (models/ms_sw_n_est.py:80-82)
+__global__ void switch_finish_kernel(const float* __restrict__ logits, int lstride, int B, float threshold,
+                                     float* __restrict__ probs, int32_t* __restrict__ expert,
+                                     int32_t* __restrict__ counts, int32_t* __restrict__ lists) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float noise = logits[(size_t)b * lstride];
+  const int pick = (noise < threshold) ? 0 : 1;   // a NaN compares false -> large, like tf.where
+  if (probs) probs[b] = noise;
+  if (expert) expert[b] = pick;
+  if (counts) {
+    const int pos = atomicAdd(&counts[pick], 1);
+    lists[(size_t)pick * B + pos] = b;
+  }
+}
+
 __global__ void route_kernel(const int32_t* __restrict__ expert, int B, int E,
                              int32_t* __restrict__ counts, int32_t* __restrict__ lists) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,6 +166,16 @@ int launch_gate_finish(const float* logits, int lstride, int B, int E, float* pr
   if (E > NESTI_MAX_EXPERTS) NESTI_FAIL("gate_finish: too many experts");
   if (counts) NESTI_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * E, stream));
   hipLaunchKernelGGL(gate_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, E,
+                     probs, expert, counts, lists);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_switch_finish(const float* logits, int lstride, int B, float threshold, float* probs, int32_t* expert,
+                         int32_t* counts, int32_t* lists, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (counts) NESTI_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * 2, stream));
+  hipLaunchKernelGGL(switch_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, threshold,
                      probs, expert, counts, lists);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .config import ARCH_EXPERTS, DTYPES, NestiConfig
+from .config import ARCH_EXPERTS, ARCH_MULTI, ARCH_SINGLE, DTYPES, NestiConfig
 
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
 
@@ -126,10 +126,11 @@ class NestiNet:
         return mups_forward(self.cfg, points, n_eff, out_dtype=self.dtype, out_cstride=self.mups_cstride, stream=stream)
 
     def gate(self, mups, stream=None):
-        """``scale_manager_net`` + arg-max -> (probs [B,E] f32, expert [B] int32)."""
+        """``scale_manager_net`` + arg-max -> (probs [B,E] f32, expert [B] int32); for ms_sw_n_est
+        ``noise_est_net`` + threshold -> (noise_est [B,1] f32, tower [B] int32: 0 small / 1 large)."""
         B = mups.shape[0]
         ws = self.reserve(B)
-        E = self.cfg.n_experts
+        E = self.cfg.n_gate_out
         probs = torch.empty((B, E), dtype=torch.float32, device=self.device)
         expert = torch.empty((B,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
@@ -143,7 +144,7 @@ class NestiNet:
         expert=[B] int32 -> top-1 routed normals [B,3]."""
         B = mups.shape[0]
         ws = self.reserve(B)
-        E = 1 if self.cfg.arch != ARCH_EXPERTS else self.cfg.n_experts
+        E = self.cfg.n_towers
         if expert is None:
             out = torch.empty((E, B, 3), dtype=torch.float32, device=self.device)
             ex = None
@@ -163,14 +164,14 @@ class NestiNet:
         ``transpose(experts_prob)`` of ``test_n_est_w_experts.py:148-152``."""
         B = points.shape[0]
         ws = self.reserve(B) if ws is None else ws
-        E = self.cfg.n_experts
+        E = self.cfg.n_gate_out
         points = points.contiguous()
         if points.dtype != torch.float32:
             points = points.float()
         n_eff_i = n_eff if (n_eff.dtype == torch.int32 and n_eff.is_contiguous()) else n_eff.to(torch.int32).contiguous()
         if n_eff_i.dim() == 1:
             n_eff_i = n_eff_i.view(B, 1)       # ss_norm_est feeds a (B,) placeholder (models/ss_norm_est.py:30)
-        if self.cfg.arch != ARCH_EXPERTS:      # single tower, no gate: n_pred only (test_n_est.py:136-141)
+        if self.cfg.arch in (ARCH_SINGLE, ARCH_MULTI):      # single tower, no gate: n_pred only (test_n_est.py:136-141)
             normals = out[0] if out is not None else torch.empty((B, 3), dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.nesti_forward(self._handle, _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(ws),

@@ -5,7 +5,7 @@ query) -> MuPS -> gating -> top-1 expert -> normals.  This is the body of the re
 import numpy as np
 import torch
 
-from .config import ARCH_EXPERTS, NestiConfig
+from .config import ARCH_MULTI, ARCH_SINGLE, NestiConfig
 from .model import NestiNet
 from .provider import CloudPatches
 
@@ -19,7 +19,7 @@ class NormalEstimator:
                  use_graph=False, n_streams=1):
         self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
         self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=self.batch)
-        S, P, E = cfg.n_scales, cfg.num_point, cfg.n_experts
+        S, P, E = cfg.n_scales, cfg.num_point, max(1, cfg.n_gate_out)
         self._points = torch.empty((self.batch, S * P, 3), dtype=torch.float32, device=self.device)
         self._n_eff = torch.empty((self.batch, S), dtype=torch.int32, device=self.device)
         # n_streams > 1: consecutive batches alternate between HIP streams (own staging buffers and scratch
@@ -57,17 +57,18 @@ class NormalEstimator:
     def run(self, cloud: CloudPatches, first=0, count=None, out=None):
         """Normals for patch rows [first, first+count) of a prepared cloud.
 
-        Returns (normals [count,3] f32, expert [count] int32, probs [count,E] f32) on the device;
+        Returns (normals [count,3] f32, expert [count] int32, probs [count,E] f32) on the device
+        (ms_sw_n_est: expert = tower picked by the noise threshold, probs = noise_est [count,1]);
         everything is enqueued on the current stream, nothing synchronises."""
         count = cloud.patch_count - first if count is None else count
-        E = self.cfg.n_experts
+        E = max(1, self.cfg.n_gate_out)
         if out is None:
             normals = torch.empty((count, 3), dtype=torch.float32, device=self.device)
             expert = torch.empty((count,), dtype=torch.int32, device=self.device)
             probs = torch.empty((count, E), dtype=torch.float32, device=self.device)
         else:
             normals, expert, probs = out
-        single_tower = self.cfg.arch != ARCH_EXPERTS      # ss/ms ablations: normals only
+        single_tower = self.cfg.arch in (ARCH_SINGLE, ARCH_MULTI)      # ss/ms ablations: normals only
         done, it = 0, 0
         main = torch.cuda.current_stream(self.device)
         if self.n_streams > 1:

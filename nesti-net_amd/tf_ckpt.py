@@ -199,15 +199,23 @@ def _load_py2_pickle(path):
 
 
 def load_parameters(path):
-    """``parameters.p`` -> NestiConfig (``test_n_est_w_experts.py:46-54``)."""
+    """``parameters.p`` (the pickled argparse namespace of the training script) -> NestiConfig
+    (``test_n_est_w_experts.py:46-54``, ``test_n_est.py:35-42``, ``test_n_est_w_switching.py:31-37``)."""
     ns = _load_py2_pickle(path)
-    ed = json.loads(ns.expert_dict)                                      # JSON-in-JSON, :53-54
-    ed = {int(k): (json.loads(v) if isinstance(v, str) else v) for k, v in ed.items()}
     variance = getattr(ns, "gmm_variance", 0.0156)
-    n_gauss = getattr(ns, "n_gaussians", 8)
-    return NestiConfig(patch_radius=[float(r) for r in ns.patch_radius], num_point=int(ns.num_point),
-                       n_gaussians=int(n_gauss), gmm_variance=float(variance), n_experts=int(ns.n_experts),
-                       expert_dict=ed)
+    n_gauss = getattr(ns, "num_gaussians", getattr(ns, "n_gaussians", 8))   # train_*.py: --num_gaussians
+    model = getattr(ns, "model", "experts_n_est")
+    radius = [float(r) for r in ns.patch_radius]
+    common = dict(patch_radius=radius, num_point=int(ns.num_point), n_gaussians=int(n_gauss), gmm_variance=float(variance))
+    if model == "experts_n_est":
+        ed = json.loads(ns.expert_dict)                                      # JSON-in-JSON, :53-54
+        ed = {int(k): (json.loads(v) if isinstance(v, str) else v) for k, v in ed.items()}
+        return NestiConfig(n_experts=int(ns.n_experts), expert_dict=ed, **common)
+    base = NestiConfig.for_model(model)                                      # raises on an unknown model name
+    if model == "ss_norm_est" and len(radius) != 1:
+        raise ValueError("ss_norm_est takes one patch radius, parameters.p has %s" % radius)
+    ed = {0: list(range(len(radius)))} if base.n_experts == 1 else base.expert_dict
+    return NestiConfig(n_experts=base.n_experts, expert_dict=ed, arch=base.arch, **common)
 
 
 def load_gmm(path):

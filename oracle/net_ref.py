@@ -150,6 +150,40 @@ def single_forward(mups, W, dtype=torch.float64):
     return fc(g, W, "fc4", dtype, bn=False, relu=False)            # :86
 
 
+def _ss_tower(x, W, sfx, dtype, last_relu):
+    """The tower shared by ``noise_est_net`` / ``normal_est_net`` of ``models/ms_sw_n_est.py:139-215``
+    (= ``single_forward`` with scope suffix ``sfx``)."""
+    x = inception(x, W, "inception1" + sfx, 3, 5, dtype)
+    x = inception(x, W, "inception2" + sfx, 3, 5, dtype)
+    x = inception(x, W, "inception3" + sfx, 3, 5, dtype)
+    x = max_pool3d_2(x)
+    x = inception(x, W, "inception5" + sfx, 3, 5, dtype)
+    x = inception(x, W, "inception6" + sfx, 3, 5, dtype)
+    x = max_pool3d_2(x)
+    g = x.reshape(x.shape[0], -1)
+    g = fc(g, W, "fc1" + sfx, dtype)
+    g = fc(g, W, "fc2" + sfx, dtype)
+    g = fc(g, W, "fc3" + sfx, dtype)
+    return fc(g, W, "fc4" + sfx, dtype, bn=False, relu=last_relu)
+
+
+SWITCH_THRESHOLD = 0.015   # models/ms_sw_n_est.py:80
+
+
+def switch_forward(mups, W, dtype=torch.float64):
+    """``ms_sw_n_est.get_model`` after the two 3DmFVs (``models/ms_sw_n_est.py:75-82``): MuPS
+    [B,8,8,8,40] (small scale = channels 0..19, large = 20..39) ->
+    dict(noise [B], pick [B] (0 small / 1 large), normals [B,3], n_small, n_large)."""
+    x = _t(mups, dtype)
+    small, large = x[..., 0:20], x[..., 20:40]
+    noise = _ss_tower(large, W, "noise", dtype, last_relu=True)[:, 0]      # :75, relu on fc4 :172
+    n_large = _ss_tower(large, W, "large", dtype, last_relu=False)         # :77
+    n_small = _ss_tower(small, W, "small", dtype, last_relu=False)         # :78
+    mask = noise < SWITCH_THRESHOLD                                        # :80
+    normals = torch.where(mask[:, None], n_small, n_large)                 # :82
+    return {"noise": noise, "pick": (~mask).to(torch.int64), "normals": normals, "n_small": n_small, "n_large": n_large}
+
+
 def multi_forward(mups, W, n_scales, dtype=torch.float64):
     """``ms_norm_est.get_model`` after the 3DmFV (``models/ms_norm_est.py:74-140``): MuPS
     [B,8,8,8,20*S] -> normal [B,3].  Scopes carry the last scale index (``'inception_s'+str(s)``, ``:79``)."""

@@ -63,6 +63,31 @@ def test_describe_matches_reference_graph():
     assert abs(n_params - 178.3e6) < 0.1e6
 
 
+def test_describe_switching_model_graph():
+    """ms_sw_n_est (models/ms_sw_n_est.py:41-215): three 'ss' towers with scope suffixes noise / small / large."""
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import _lib, weights
+    from nesti_net_amd.config import ARCH_SWITCH, NestiConfig
+    cfg = NestiConfig.for_model("ms_sw_n_est")
+    assert cfg.arch == ARCH_SWITCH and cfg.n_towers == 2 and cfg.n_gate_out == 1
+    d = weights.describe(cfg)
+    for sfx in ("noise", "small", "large"):
+        assert d["inception1%s_conv1/weights" % sfx] == (1, 1, 1, 20, 128)
+        assert d["inception3%s_conv3/weights" % sfx] == (5, 5, 5, 256, 128)
+        assert d["inception6%s_conv3/weights" % sfx] == (5, 5, 5, 512, 256)
+        assert d["fc1%s/weights" % sfx] == (12288, 1024)
+        assert "fc4%s/bn/beta" % sfx not in d
+    assert d["fc4noise/weights"] == (128, 1) and d["fc4small/weights"] == (128, 3) and d["fc4large/weights"] == (128, 3)
+    assert not any("inception4" in k or "inception7" in k for k in d)          # 4 and 7 are the max-pools
+    lib = _lib.load()
+    bad = NestiConfig.for_model("ms_sw_n_est")
+    bad.patch_radius = [0.01, 0.03, 0.05]
+    n = ctypes.c_int(0)
+    c = bad.to_c()
+    assert lib.nesti_model_describe(ctypes.byref(c), ctypes.byref(n), None, 0) != 0
+    assert b"two scales" in lib.nesti_last_error()
+
+
 def test_config_expert_dict_and_errors():
     import nesti_net_amd  # noqa: F401
     from nesti_net_amd import _lib

@@ -235,6 +235,56 @@ def test_multi_scale_ablation_matches_oracle(gpu_device):
     assert np.all(1 - c < COS_TOL_F32)
 
 
+def test_switching_model_matches_oracle(gpu_device):
+    """ms_sw_n_est (N4): noise_est_net on the large scale thresholds at 0.015 between the 'small' and 'large'
+    normal towers (models/ms_sw_n_est.py:75-82).  fc4noise's bias is set so that the synthetic noise estimate
+    straddles the threshold and both towers are exercised."""
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from oracle import mups_ref, net_ref
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid20k" in p][0])
+    cfg = NestiConfig.for_model("ms_sw_n_est")
+    W = weights.synthetic_weights(cfg)
+    B = 8
+    pts = np.concatenate([g["points"][:B, 0:512], g["points"][:B, 1024:1536]], axis=1)     # radii 0.01 and 0.05
+    n_eff = np.stack([g["n_eff"][:B, 0], g["n_eff"][:B, 2]], axis=1)
+    mups_o = mups_ref.mups_assemble(pts, n_eff, 2)
+    pre = net_ref._ss_tower(torch.as_tensor(mups_o[..., 20:40], dtype=torch.float64), W, "noise", torch.float64, False)[:, 0]
+    srt = np.sort(pre.numpy())
+    W["fc4noise/biases"] = (W["fc4noise/biases"] + 0.015 - 0.5 * (srt[B // 2 - 1] + srt[B // 2])).astype(np.float32)
+    ref = net_ref.switch_forward(mups_o, W, dtype=torch.float64)
+    pick_ref = ref["pick"].numpy()
+    assert 0 < pick_ref.sum() < B, "calibration should exercise both towers"
+    margin = np.abs(ref["noise"].numpy() - 0.015)
+    net = NestiNet(cfg, W, dtype="f32", device=gpu_device, max_batch=B)
+    p_d, n_d = torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device)
+    normals, pick, noise = net(p_d, n_d)
+    torch.cuda.synchronize()
+    assert noise.shape == (B, 1)
+    err = np.abs(noise.cpu().numpy()[:, 0] - ref["noise"].numpy())
+    print("ms_sw_n_est noise err", err.max(), "margins", margin.min())
+    assert err.max() < 2e-5
+    safe = margin > 2e-5
+    assert np.array_equal(pick.cpu().numpy()[safe], pick_ref[safe])
+    c = _cos(normals.cpu().numpy()[safe], ref["normals"].numpy()[safe])
+    assert np.all(1 - c < COS_TOL_F32)
+    # both towers on every point == [n_est_small, n_est_large] (the tensors tf.where chooses from, :82)
+    mups = net.mups(p_d, n_d)
+    both = net.experts(mups, None).cpu().numpy()
+    assert both.shape == (2, B, 3)
+    assert np.all(1 - _cos(both[0], ref["n_small"].numpy()) < COS_TOL_F32)
+    assert np.all(1 - _cos(both[1], ref["n_large"].numpy()) < COS_TOL_F32)
+    noise2, pick2 = net.gate(mups)
+    assert torch.equal(pick2, pick) and torch.equal(noise2, noise)
+    # production dtype
+    net16 = NestiNet(cfg, W, dtype="bf16", device=gpu_device, max_batch=B)
+    n16, p16, z16 = net16(p_d, n_d)
+    same = p16.cpu().numpy() == pick_ref
+    assert np.all(1 - _cos(n16.cpu().numpy()[same], ref["normals"].numpy()[same]) < 2e-3)
+    assert np.all(same | (margin < 5e-3))
+
+
 def test_other_expert_layouts_match_oracle(gpu_device):
     """The graph builder follows expert_dict / n_experts generically (models/experts_n_est.py:83-103): 4 experts
     {0:[0], 1:[1,2], 2:[2], 3:[0,1,2]} -- a 2-scale expert gets 128/2 = 64 first-block filters."""

@@ -64,6 +64,30 @@ def test_patches_batching_invariance_and_dense_queries(gpu_device):
     assert np.all(d <= r_abs[2] * (1 + 1e-12))
 
 
+@pytest.mark.parametrize("shape,noise,density", [
+    ("sphere", 0.0, None), ("ellipsoid", 0.00125, None), ("torus", 0.006, None), ("box", 0.012, None),   # BASELINE cfg 3: PCPNet noise levels
+    ("sphere", 0.0, "gradient"), ("box", 0.0, "striped"), ("torus", 0.00125, "gradient")])             # cfg 4: varying-density sets
+def test_patches_pcpnet_noise_levels_and_density_sets(shape, noise, density, gpu_device):
+    """Ball sets / n_eff / neighbour order / patch coordinates bit-exact against the (reference-pinned) oracle on
+    the PCPNet noise levels and the gradient / striped density sets, where ball sizes swing between a handful
+    of points and far more than P."""
+    from nesti_net_amd import synth
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.provider import CloudPatches
+    from oracle import patches_ref
+    pts, _ = synth.make_cloud(shape, n=30000, seed=11, noise=noise, density=density)
+    cfg = NestiConfig()
+    q = np.arange(0, 30000, 233)
+    cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
+    got = [t.cpu().numpy() for t in cp.build(0, len(q), want_idx=True)]
+    ref = patches_ref.extract_patches(pts, q, cp.r_abs, cfg.num_point, cp.seed)
+    assert np.array_equal(got[3], ref[3]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32))
+    assert got[3][:, 2].max() > cfg.num_point          # the subsample branch is exercised
+    if density is not None:
+        assert got[3][:, 2].max() > 4 * max(1, got[3][:, 2].min())   # density really varies
+
+
 def test_patches_tiny_and_degenerate_clouds(gpu_device):
     from nesti_net_amd.config import NestiConfig
     from nesti_net_amd.provider import CloudPatches

@@ -136,3 +136,18 @@ def test_cli_single_scale_model(dataset_dir, tmp_path, gpu_device):
     normals = np.loadtxt(os.path.join(out, "shapeA.normals"))
     assert normals.shape == (len(range(0, 3000, 7)), 3) and np.all(np.isfinite(normals))
     assert not os.path.exists(os.path.join(out, "shapeA.experts"))
+
+
+def test_cli_switching_model(dataset_dir, tmp_path, gpu_device):
+    """--model ms_sw_n_est (the reference's test_n_est_w_switching.py path): two radii, .normals only (:158)."""
+    from nesti_net_amd.cli import main
+    results = str(tmp_path / "log_sw") + os.sep
+    os.makedirs(results)
+    rc = main(["--results_path", results, "--model", "ms_sw_n_est", "--dataset_name", "synth", "--dataset_path", dataset_dir,
+               "--testset", "testset.txt", "--sparse_patches", "1", "--synthetic_weights", "--dtype", "f16"])
+    assert rc == 0
+    out = os.path.join(results, "synth_results")
+    for nm, n in (("shapeA", 3000), ("shapeB", 2500)):
+        normals = np.loadtxt(os.path.join(out, nm + ".normals"))
+        assert normals.shape == (len(range(0, n, 7)), 3) and np.all(np.isfinite(normals))
+        assert not os.path.exists(os.path.join(out, nm + ".experts"))

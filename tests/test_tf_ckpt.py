@@ -121,7 +121,8 @@ def test_py2_pickles_and_full_model_dir(tmp_path, monkeypatch):
     from nesti_net_amd import tf_ckpt, weights
     from nesti_net_amd.config import NestiConfig
     cfg = NestiConfig()
-    ns = argparse.Namespace(patch_radius=[0.01, 0.03, 0.05], num_point=512, n_experts=7, n_gaussians=8, gmm_variance=0.0156,
+    ns = argparse.Namespace(patch_radius=[0.01, 0.03, 0.05], num_point=512, n_experts=7, num_gaussians=8, gmm_variance=0.0156,
+                            model="experts_n_est",
                             expert_loss_type="simple", loss_type="cos",
                             expert_dict=json.dumps({str(k): json.dumps(v) for k, v in cfg.expert_dict.items()}))
     pickle.dump(ns, open(str(tmp_path / "parameters.p"), "wb"), protocol=2)
@@ -139,6 +140,15 @@ def test_py2_pickles_and_full_model_dir(tmp_path, monkeypatch):
         del sys.modules["sklearn.mixture.gaussian_mixture"]
     cfg2 = tf_ckpt.load_parameters(str(tmp_path / "parameters.p"))
     assert cfg2 == cfg
+    # the ablation drivers pickle the same kind of namespace, without expert fields
+    # (train_n_est.py:99, train_n_est_w_switching.py:111); --model selects the graph
+    for model, radius in (("ss_norm_est", [0.05]), ("ms_norm_est", [0.01, 0.03, 0.05]), ("ms_sw_n_est", [0.01, 0.05])):
+        ns_a = argparse.Namespace(patch_radius=radius, num_point=512, num_gaussians=8, gmm_variance=0.0156, model=model)
+        pickle.dump(ns_a, open(str(tmp_path / "parameters_a.p"), "wb"), protocol=2)
+        got = tf_ckpt.load_parameters(str(tmp_path / "parameters_a.p"))
+        want = NestiConfig.for_model(model)
+        assert got.arch == want.arch and got.patch_radius == radius and got.n_towers == want.n_towers
+        weights.describe(got)          # the graph builder accepts it
     w, mu, cov = tf_ckpt.load_gmm(str(tmp_path / "gmm.p"))
     assert w.shape == (512,) and cov[0, 0] == 0.0156
     # a whole trained-model directory; the real graph's variable list restricted to its small tensors
