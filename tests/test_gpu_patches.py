@@ -75,9 +75,9 @@ def test_patches_pcpnet_noise_levels_and_density_sets(shape, noise, density, gpu
     from nesti_net_amd.config import NestiConfig
     from nesti_net_amd.provider import CloudPatches
     from oracle import patches_ref
-    pts, _ = synth.make_cloud(shape, n=30000, seed=11, noise=noise, density=density)
+    pts, _ = synth.make_cloud(shape, n=100000, seed=11, noise=noise, density=density)
     cfg = NestiConfig()
-    q = np.arange(0, 30000, 233)
+    q = np.arange(0, 100000, 773)
     cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
     got = [t.cpu().numpy() for t in cp.build(0, len(q), want_idx=True)]
     ref = patches_ref.extract_patches(pts, q, cp.r_abs, cfg.num_point, cp.seed)
