@@ -76,6 +76,34 @@ __device__ __forceinline__ void glds16(const unsigned char* src, unsigned lds_ds
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Row (within the workgroup's 512) that lane-row l of MFMA tile (wave, mi) owns.
+// remap == 0: tile t = 2*wave + mi holds rows [32t, 32t+32).
+// remap == 1: a padding tap skips whole tiles, and a SIMD's matrix pipe serves waves c and c+4, so the tiles are
+//   shaped to be skippable and dealt to the SIMDs as a Latin square (SIMD c gets one tile of every z slab and one
+//   of every y slab): every tap then leaves all four pipes (nearly) the same number of live tiles.
+//   8^3: tile = x 0..7 x y pair yp x z pair s, s = 2*(wave>>2) + mi, yp = (c - s) & 3, c = wave & 3;
+//   4^3: tile = x 0..3 x y pair yp x plane z = s of the 4 points of group pg, 2*yp + pg = (c - s) & 3.
+__device__ __forceinline__ int tile_row(int remap, int log2S, int wave, int mi, int l) {
+  if (!remap) return wave * 64 + mi * 32 + l;
+  const int c = wave & 3, s = 2 * (wave >> 2) + mi;
+  const int q = (c - s) & 3;
+  if (log2S == 3) return ((2 * s + (l >> 4)) << 6) + ((2 * q + ((l >> 3) & 1)) << 3) + (l & 7);
+  return (((q & 1) * 4 + (l >> 3)) << 6) + (s << 4) + ((2 * (q >> 1) + ((l >> 2) & 1)) << 2) + (l & 3);
+}
+// 16-B slot swizzle key of an LDS input row: the rows one ds_read_b128 lane group touches must differ in
+// (row & 1, key).  Natural and 8^3 tiles: four runs of 4 consecutive rows that differ in row bits 2..3; remapped 4^3
+// tiles: runs of 4 rows from 4 different points (row bits 6..7).
+// Branch-free: key = ((row >> 1) & m_lo) | (((row >> 6) & m_hi) << 1) with (m_lo, m_hi) = (7, 0) or (1, 3).
+struct SwzKey {
+  int m_lo, m_hi;
+  __device__ __forceinline__ SwzKey(int remap, int log2S) {
+    const bool pts = remap && log2S == 2;
+    m_lo = pts ? 1 : 7;
+    m_hi = pts ? 3 : 0;
+  }
+  __device__ __forceinline__ int operator()(int row) const { return ((row >> 1) & m_lo) | (((row >> 6) & m_hi) << 1); }
+};
+
 template <int DT, int TN, bool KPIPE>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -100,6 +128,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   if (m_tile >= p.m_tiles) return;
   int npts = p.npoints;
   if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
+  const int remap = KPIPE ? 0 : p.remap;
+  const SwzKey swz_key(remap, p.log2S);
   const int log2S = p.log2S, log2V = 3 * log2S;
   const int S = 1 << log2S, V = 1 << log2V;
   const long long total_rows = (long long)npts << log2V;
@@ -111,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int row_l = (wave * 8 + j) * 8 + (lane >> 3);
-    const int slot = (lane & 7) ^ ((row_l >> 1) & 7);       // inverse swizzle on the SOURCE
+    const int slot = (lane & 7) ^ swz_key(row_l);   // inverse swizzle on the SOURCE
     const long long gr = r0 + row_l;
     if (gr < total_rows) {
       long long pt = gr >> log2V;
@@ -146,7 +176,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   int rz[2], ry[2], rx[2], rrow[2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    rrow[mi] = wave * 64 + mi * 32 + (lane & 31);
+    rrow[mi] = tile_row(remap, log2S, wave, mi, lane & 31);
     const int vox = rrow[mi] & (V - 1);
     rz[mi] = vox >> (2 * log2S);
     ry[mi] = (vox >> log2S) & (S - 1);
@@ -166,8 +196,10 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 
   // one (chunk, tap) step: 4 K-steps of 2 x NI MFMAs; the fragments of K-step kk+1 are read from LDS
   // before the MFMAs of K-step kk are issued, so the LDS latency hides behind the matrix pipe.
-  auto compute = [&](const unsigned char* Acur, const unsigned char* Bcur, const int (&a_addr)[2],
-                     const int (&a_sw)[2]) __attribute__((always_inline)) {
+  // live0 / live1 (wave-uniform): which of the wave's two M tiles take part in this tap; a dead tile's MFMAs are
+  // branched over (its fragment reads hit the zero row).
+  auto compute = [&](const bool live0, const bool live1, const unsigned char* Acur, const unsigned char* Bcur,
+                     const int (&a_addr)[2], const int (&a_sw)[2]) __attribute__((always_inline)) {
     uint4 a[2][2], b[2][NI];
     auto load_frags = [&](int kk, uint4 (&af)[2], uint4 (&bf)[NI]) __attribute__((always_inline)) {
       const int slot = kk * 2 + khalf;
@@ -183,10 +215,14 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) load_frags(kk + 1, a[(kk + 1) & 1], b[(kk + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this K-step's MFMAs (hipcc sinks it otherwise)
+      if (KPIPE || live0) {
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+        for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[0][ni], a[kk & 1][0], b[kk & 1][ni]);
+      }
+      if (KPIPE || live1) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[mi][ni], a[kk & 1][mi], b[kk & 1][ni]);
+        for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[1][ni], a[kk & 1][1], b[kk & 1][ni]);
+      }
     }
   };
 
@@ -194,7 +230,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
     // ---- one tap: software pipeline over input-channel chunks --------------------------------
     int a_addr[2], a_sw[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) { a_addr[mi] = rrow[mi] * kRowBytes; a_sw[mi] = (rrow[mi] >> 1) & 7; }
+    for (int mi = 0; mi < 2; ++mi) { a_addr[mi] = rrow[mi] * kRowBytes; a_sw[mi] = swz_key(rrow[mi]); }
     stage_a(0, 0);
     stage_b(0, 0, 0);
     wait_vm0();
@@ -205,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
         stage_a(c + 1, cur ^ 1);
         stage_b(c + 1, 0, cur ^ 1);
       }
-      compute(As + cur * kABytes, Bs + cur * kBTile, a_addr, a_sw);
+      compute(true, true, As + cur * kABytes, Bs + cur * kBTile, a_addr, a_sw);
       wait_vm0();
       __syncthreads();
     }
@@ -235,18 +271,17 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           const int dz = p.tap[t][0], dy = p.tap[t][1], dx = p.tap[t][2];
           const int shift = dz * (1 << (2 * log2S)) + dy * S + dx;
           int a_addr[2], a_sw[2];
-          bool any_ok = false;
+          bool live[2];
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
             const bool ok = ((unsigned)(rz[mi] + dz) < (unsigned)S) & ((unsigned)(ry[mi] + dy) < (unsigned)S) &
                             ((unsigned)(rx[mi] + dx) < (unsigned)S);
             const int srow = rrow[mi] + shift;
             a_addr[mi] = ok ? srow * kRowBytes : kZeroOff;   // padding tap -> the zero row
-            a_sw[mi] = ok ? ((srow >> 1) & 7) : 0;
-            any_ok |= ok;
+            a_sw[mi] = ok ? swz_key(srow) : 0;
+            live[mi] = __ballot(ok) != 0ull;                 // an all-padding tile issues no MFMAs
           }
-          if (__ballot(any_ok) != 0ull)   // a whole-wave padding tap (z-plane halo) issues no MFMAs
-            compute(As, Bs + (grp_cur * 2 + u) * kBTile, a_addr, a_sw);
+          if (live[0] | live[1]) compute(live[0], live[1], As, Bs + (grp_cur * 2 + u) * kBTile, a_addr, a_sw);
         }
         wait_vm0();
         __syncthreads();
@@ -417,7 +452,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           const float bv = bias[ni * 32 + (lane & 31)];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int row = wave * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const int row = tile_row(remap, log2S, wave, mi, (r & 3) + 8 * (r >> 2) + 4 * khalf);
             *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = fmaxf(acc[mi][ni][r] + bv, act_floor);
           }
         }
@@ -476,14 +511,14 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           *reinterpret_cast<float*>(scratch + row * kPoolStride + col * 4) = fmaxf(acc[mi][ni][r] + bv, act_floor);
         }
       }
-      const long long gr0 = r0 + wave * 64 + mi * 32;
       if (out_esz == 4) {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {                     // 16 lanes x 16 B = one 64-float row segment
           const int row = it * 4 + (lane >> 4), cpos = lane & 15;
           const uint4 v = *reinterpret_cast<const uint4*>(scratch + row * kPoolStride + cpos * 16);
-          if (gr0 + row < total_rows)
-            *reinterpret_cast<uint4*>(out_b + ((gr0 + row) * p.out_cstride + out_col0 + nh * 64) * 4 + cpos * 16) = v;
+          const long long gr = r0 + tile_row(remap, log2S, wave, mi, row);
+          if (gr < total_rows)
+            *reinterpret_cast<uint4*>(out_b + (gr * p.out_cstride + out_col0 + nh * 64) * 4 + cpos * 16) = v;
         }
       } else {
         using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
@@ -493,8 +528,9 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           const float4 f0 = *reinterpret_cast<const float4*>(scratch + row * kPoolStride + cpos * 32);
           const float4 f1 = *reinterpret_cast<const float4*>(scratch + row * kPoolStride + cpos * 32 + 16);
           const uint4 v = make_uint4(E::pack2(f0.x, f0.y), E::pack2(f0.z, f0.w), E::pack2(f1.x, f1.y), E::pack2(f1.z, f1.w));
-          if (gr0 + row < total_rows)
-            *reinterpret_cast<uint4*>(out_b + ((gr0 + row) * p.out_cstride + out_col0 + nh * 64) * 2 + cpos * 16) = v;
+          const long long gr = r0 + tile_row(remap, log2S, wave, mi, row);
+          if (gr < total_rows)
+            *reinterpret_cast<uint4*>(out_b + (gr * p.out_cstride + out_col0 + nh * 64) * 2 + cpos * 16) = v;
         }
       }
     }

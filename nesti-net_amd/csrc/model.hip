@@ -2,6 +2,7 @@
 // (models/experts_n_est.py:40-314) expressed as a list of kernel launches, batch-norm folding
 // and weight repacking for the MFMA kernels, and the workspace planner.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <functional>
@@ -510,6 +511,16 @@ size_t tower_bytes(const Tower& T, int NB, int dtype) {
   return s;
 }
 
+// Which k^3 layers use the Latin-square tile layout (kernels.h: ConvParams::remap): those where a 32-row tile can
+// fall entirely on padding -- 5^3 taps at 8^3 (|d| = 2 clears a y/z pair) and every multi-tap layer at 4^3.  3^3 at
+// 8^3 only ever clears single planes, which no 32-row tile shape can balance over four SIMDs.
+int conv_remap(int k, int log2S, int n_taps) {
+  static const int force = [] { const char* e = getenv("NESTI_CONV_REMAP"); return e ? atoi(e) : -1; }();
+  if (n_taps <= 1 || (log2S != 2 && log2S != 3)) return 0;
+  if (force >= 0) return force ? 1 : 0;
+  return (log2S == 2 || k >= 4) ? 1 : 0;
+}
+
 struct RunCtx {
   const nesti_model* m;
   int NB;                        // capacity (points)
@@ -547,6 +558,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
       if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C; p.mp_mode = op.mp_mode; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
+      p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
       prof_begin(NESTI_PROF_CONV, rc.stream);
       const int rcv = launch_conv(p, dtype, pl.TN, rc.stream);
       prof_end(NESTI_PROF_CONV, rc.stream);
