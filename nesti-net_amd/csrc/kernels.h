@@ -47,6 +47,8 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream);
+// multi-tap layers with 128-column tiles whose weights are packed fragment-major (conv_taps.hip)
+int launch_conv_taps(const ConvParams& p, int dtype, hipStream_t stream);
 
 struct PoolParams {
   const void* in;

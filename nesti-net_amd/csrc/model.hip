@@ -344,6 +344,7 @@ struct PackedLayer {
   void* wpk = nullptr;
   float* bias = nullptr;
   int TN = 64, n_tiles = 0, split_tile = 0, n_chunks = 0, n_taps = 0;
+  bool frag_major = false;   // weights in conv_taps_kernel's per-wave fragment order
   int8_t tap[kMaxTaps][4];
 };
 
@@ -426,6 +427,13 @@ int fold_layer(const LayerDesc& d, const std::string& scope, const TensorTable& 
   return 0;
 }
 
+// NESTI_CONV_TAPS=1 routes the multi-tap layers with 128-column tiles to the barrier-free kernel of conv_taps.hip
+// (parity-tested, but measured 12 % slower end to end than conv_igemm_kernel -- DESIGN.md 4.3 -- so it is opt-in)
+bool use_taps_kernel(int n_taps, int TN) {
+  static const int on = [] { const char* e = getenv("NESTI_CONV_TAPS"); return e ? atoi(e) : 0; }();
+  return on && n_taps > 1 && TN == 128;
+}
+
 int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer* pl) {
   const int n_parts = d.scope2.empty() ? 1 : 2;
   Folded parts[2];
@@ -461,6 +469,7 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
   const size_t total = (size_t)pl->n_tiles * pl->n_chunks * pl->n_taps * tile_bytes;
   std::vector<unsigned char> host(total, 0);
   const int per_slot = 16 / (int)esz;
+  pl->frag_major = n_parts == 1 && use_taps_kernel(pl->n_taps, pl->TN);
   for (int nt = 0; nt < pl->n_tiles; ++nt) {
     const int part = (nt * pl->TN) / part_p;
     const int n_base = nt * pl->TN - part * part_p;    // first real channel of this tile within its part
@@ -478,7 +487,11 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
             const int n = n_base + nl;
             if (n >= d.cout) break;
             const float v = wrow[n] * f.scale[n];
-            unsigned char* dst = tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
+            // conv_igemm_kernel: LDS image, row nl, 16-B slot XOR-swizzled.  conv_taps_kernel: [column group of 32]
+            // [K-step][lane = 32 * (slot & 1) + column][16 B], one contiguous 1-KiB wave load per K-step.
+            unsigned char* dst = pl->frag_major
+                ? tile + (size_t)(nl >> 5) * 4096 + (size_t)(slot >> 1) * 1024 + (size_t)((slot & 1) * 32 + (nl & 31)) * 16 + within * esz
+                : tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
             if (dtype == NESTI_F32) memcpy(dst, &v, 4);
             else {
               const uint16_t h = (dtype == NESTI_BF16) ? host_f32_to_bf16(v) : host_f32_to_f16(v);
@@ -560,7 +573,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
       prof_begin(NESTI_PROF_CONV, rc.stream);
-      const int rcv = launch_conv(p, dtype, pl.TN, rc.stream);
+      const int rcv = pl.frag_major ? launch_conv_taps(p, dtype, rc.stream) : launch_conv(p, dtype, pl.TN, rc.stream);
       prof_end(NESTI_PROF_CONV, rc.stream);
       if (rcv) return 1;
     } else {

@@ -1,0 +1,28 @@
+#!/bin/bash
+# SQ counters of the gating tower's conv launches (last repetition) at batch $1; extra env as $2 (e.g. NESTI_CONV_TAPS=0)
+cd /tmp && export TMPDIR=/tmp
+B=${1:-2048}
+[ -n "$2" ] && export $2
+out=/tmp/pg_$RANDOM
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/scripts/prof_gate.py $B 2 > $out.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d ${out}b -- python3 $GRAFT_REPO_ROOT/scripts/prof_gate.py $B 2 > ${out}b.log 2>&1
+python3 - $out ${out}b <<'PY'
+import csv, sys, glob, collections
+def load(d):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    by = collections.OrderedDict()
+    for r in rows:
+        k = (int(r["Dispatch_Id"]), r["Kernel_Name"].replace("void nesti::(anonymous namespace)::", "").split("(")[0], int(r["Grid_Size"]) // int(r["Workgroup_Size"]))
+        by.setdefault(k, {})[r["Counter_Name"]] = by.get(k, {}).get(r["Counter_Name"], 0) + float(r["Counter_Value"])
+    return by
+a, b = load(sys.argv[1]), load(sys.argv[2])
+ka = [k for k in a if "conv" in k[1]]; kb = [k for k in b if "conv" in k[1]]
+n = len(ka) // 2
+for k, k2 in list(zip(ka, kb))[n:n + 18]:
+    c, d = a[k], b[k2]
+    wc = c["SQ_WAVE_CYCLES"]
+    print("%-34s wgs %5d mfma %.3g valu %.3g salu %.3g lds %.3g | wait %.2f stall %.2f active %.2f | ldsconf %.3f ldswait %.2f vmem %.3g gui %.3g" % (
+        k[1], k[2], c["SQ_INSTS_MFMA"], c["SQ_INSTS_VALU"], c["SQ_INSTS_SALU"], c["SQ_INSTS_LDS"], c["SQ_WAIT_ANY"] / wc, c["SQ_WAIT_INST_ANY"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc,
+        d["SQ_LDS_BANK_CONFLICT"] / max(1, d["SQ_LDS_IDX_ACTIVE"]), d["SQ_WAIT_INST_LDS"] / wc, d["SQ_INSTS_VMEM_RD"], d["GRBM_GUI_ACTIVE"]))
+PY
