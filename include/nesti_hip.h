@@ -50,7 +50,7 @@ typedef struct {
   int arch;                                /* NESTI_ARCH_*                                      */
   int n_scales;                            /* len(patch_radius)                                 */
   int points_per_scale;                    /* num_point (P)                                     */
-  int grid_n;                              /* Gaussians per axis (8)                            */
+  int grid_n;                              /* Gaussians per axis: 8, or 3 (experts_n_est only)  */
   double variance;                         /* gmm covariance (0.0156)                           */
   int n_experts;                           /* E                                                 */
   int expert_scale_lo[NESTI_MAX_EXPERTS];  /* min(expert_dict[i])   models/experts_n_est.py:100 */
@@ -139,6 +139,13 @@ void nesti_model_destroy(nesti_model_t* m);
 /* Scratch size for forward calls of up to max_batch points. */
 size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch);
 int nesti_model_mups_cstride(const nesti_model_t* m); /* channel stride of the internal MuPS tensor */
+int nesti_model_mups_rows(const nesti_model_t* m);    /* rows per point of the internal MuPS tensor: 512 (8^3 grid)
+                                                       * or 64 (3^3 grid: row 16i+4j+k of a 4^3 index space, rows with
+                                                       * a coordinate of 3 are zero) */
+/* MuPS (utils/tf_util.py:655-753 + models/experts_n_est.py:66-76) of a batch in the layout and dtype
+ * nesti_gate_forward / nesti_experts_forward read: mups_out_dev is [B, nesti_model_mups_rows, nesti_model_mups_cstride]. */
+int nesti_model_mups(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B,
+                     void* mups_out_dev, void* stream);
 
 /* scale_manager_net + arg-max (models/experts_n_est.py:155-179,
  * test_n_est_w_experts.py:150): mups_dev is [B,R^3,cstride] in the model dtype.

@@ -43,6 +43,8 @@ SIGNATURES = {
     "nesti_model_destroy": (None, [_vp]),
     "nesti_workspace_bytes": (_sz, [_vp, _i]),
     "nesti_model_mups_cstride": (_i, [_vp]),
+    "nesti_model_mups_rows": (_i, [_vp]),
+    "nesti_model_mups": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "nesti_gate_forward": (_i, [_vp, _vp, _i, _vp, _sz, _vp, _vp, _vp]),
     "nesti_experts_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "nesti_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),

@@ -81,7 +81,8 @@ void prof_begin(int category, hipStream_t st);
 void prof_end(int category, hipStream_t st);
 
 // ---- launchers implemented in the .hip files -------------------------------
+// embed4: 3^3 grid only -- write rows in a 4^3 index space (64 rows per point, dead rows zero) for the conv towers
 int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n_eff, int B,
-                void* out, int out_dtype, int out_cstride, hipStream_t stream);
+                void* out, int out_dtype, int out_cstride, int embed4, hipStream_t stream);
 
 }  // namespace nesti

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   const SwzKey swz_key(remap, p.log2S);
   const int log2S = p.log2S, log2V = 3 * log2S;
   const int S = 1 << log2S, V = 1 << log2V;
+  const unsigned Sb = p.s_real ? (unsigned)p.s_real : (unsigned)S;   // real volume edge (3 inside a 4^3 index space)
   const long long total_rows = (long long)npts << log2V;
   const long long r0 = (long long)m_tile * kTileM;
   if (r0 >= total_rows) return;
@@ -241,8 +242,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           bool live[2];
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
-            const bool ok = ((unsigned)(rz[mi] + dz) < (unsigned)S) & ((unsigned)(ry[mi] + dy) < (unsigned)S) &
-                            ((unsigned)(rx[mi] + dx) < (unsigned)S);
+            const bool ok = ((unsigned)(rz[mi] + dz) < Sb) & ((unsigned)(ry[mi] + dy) < Sb) & ((unsigned)(rx[mi] + dx) < Sb);
             const int srow = rrow[mi] + shift;
             a_addr[mi] = ok ? srow * kRowBytes : kZeroOff;   // padding tap -> the zero row
             a_sw[mi] = ok ? swz_key(srow) : 0;
@@ -272,8 +272,9 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
     // windowed sums from registers.  S and K are compile-time so every load is independent.
     unsigned char* const zero16 = smem + kTileM * kPoolStride;
     if (tid < 4) reinterpret_cast<uint32_t*>(zero16)[tid] = 0u;
-    auto pool_lines = [&](auto SS, auto KK, int nh) __attribute__((always_inline)) {
-      constexpr int S_ = decltype(SS)::value, K_ = decltype(KK)::value;
+    // SR = real volume edge (== S except for the 3^3 grid embedded in 4^3: dead rows neither contribute nor count)
+    auto pool_lines = [&](auto SS, auto SRR, auto KK, int nh) __attribute__((always_inline)) {
+      constexpr int S_ = decltype(SS)::value, SR_ = decltype(SRR)::value, K_ = decltype(KK)::value;
       constexpr int lo = (K_ - 1) / 2;
       constexpr int log2S_ = (S_ == 8) ? 3 : (S_ == 4) ? 2 : 1;
 #pragma unroll 1
@@ -288,9 +289,9 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
         for (int x = 0; x < S_; ++x) colsum[x] = make_float4(0.f, 0.f, 0.f, 0.f);
         int nz = 0, ny = 0;
 #pragma unroll
-        for (int a = 0; a < K_; ++a) nz += ((unsigned)(z + a - lo) < (unsigned)S_) ? 1 : 0;
+        for (int a = 0; a < K_; ++a) nz += ((unsigned)(z + a - lo) < (unsigned)SR_) ? 1 : 0;
 #pragma unroll
-        for (int b = 0; b < K_; ++b) ny += ((unsigned)(y + b - lo) < (unsigned)S_) ? 1 : 0;
+        for (int b = 0; b < K_; ++b) ny += ((unsigned)(y + b - lo) < (unsigned)SR_) ? 1 : 0;
         // the axis whose neighbours sit in one lane's accumulators was already summed in registers (pool_half):
         // S = 8 -> y, S = 4 -> z; only the other one is walked here
         constexpr int a_lo = (S_ == 4) ? lo : 0, a_hi = (S_ == 4) ? lo + 1 : K_;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
         for (int a = a_lo; a < a_hi; ++a) {
 #pragma unroll
           for (int b = b_lo; b < b_hi; ++b) {
-            const bool ok = ((unsigned)(z + a - lo) < (unsigned)S_) & ((unsigned)(y + b - lo) < (unsigned)S_);
+            const bool ok = ((unsigned)(z + a - lo) < (unsigned)SR_) & ((unsigned)(y + b - lo) < (unsigned)SR_);
             const int nrow0 = row0 + (((a - lo) * S_ + (b - lo)) << log2S_);
             const unsigned char* base = ok ? smem + nrow0 * kPoolStride + cg * 16 : zero16;
             const int stride = ok ? kPoolStride : 0;
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
           for (int c = 0; c < K_; ++c) {
             const int xx = x + c - lo;
-            if (xx >= 0 && xx < S_) { sum[x].x += colsum[xx].x; sum[x].y += colsum[xx].y; sum[x].z += colsum[xx].z; sum[x].w += colsum[xx].w; }
+            if (xx >= 0 && xx < SR_) { sum[x].x += colsum[xx].x; sum[x].y += colsum[xx].y; sum[x].z += colsum[xx].z; sum[x].w += colsum[xx].w; }
           }
         }
         const float4 bb = *reinterpret_cast<const float4*>(bias + nh * 64 + cg * 4);
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
         for (int x = 0; x < S_; ++x) {
           int nx = 0;
 #pragma unroll
-          for (int c = 0; c < K_; ++c) nx += (x + c - lo >= 0 && x + c - lo < S_) ? 1 : 0;
-          const float inv = 1.0f / (float)(nz * ny * nx);      // taps inside the volume (utils/tf_util.py:450-454)
+          for (int c = 0; c < K_; ++c) nx += (x + c - lo >= 0 && x + c - lo < SR_) ? 1 : 0;
+          const float inv = 1.0f / (float)max(1, nz * ny * nx);   // taps inside the volume (utils/tf_util.py:450-454); 0 only on dead rows
           const float o[4] = {fmaxf(sum[x].x * inv + bb.x, act_floor), fmaxf(sum[x].y * inv + bb.y, act_floor),
                               fmaxf(sum[x].z * inv + bb.z, act_floor), fmaxf(sum[x].w * inv + bb.w, act_floor)};
           const long long gr = r0 + row0 + x;
@@ -346,8 +347,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
     // A lane's 32 accumulators of one column cover row bits {0,1} (r&3), {3,4} (r>>2) and 5 (mi): at 8^3 that is
     // the whole y axis, at 4^3 the whole z axis.  That axis of the box sum is taken here on registers (K-1 adds
     // per value, no LDS), which divides the LDS line reads of pool_lines by K.
-    auto pool_half = [&](auto NH, auto SS, auto KK) __attribute__((always_inline)) {
-      constexpr int nh = decltype(NH)::value, S_ = decltype(SS)::value, K_ = decltype(KK)::value;
+    auto pool_half = [&](auto NH, auto SS, auto SRR, auto KK) __attribute__((always_inline)) {
+      constexpr int nh = decltype(NH)::value, S_ = decltype(SS)::value, SR_ = decltype(SRR)::value, K_ = decltype(KK)::value;
       constexpr int lo = (K_ - 1) / 2;
 #pragma unroll
       for (int n2 = 0; n2 < 2; ++n2) {
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
               for (int a = 0; a < K_; ++a) {
                 const int zz = z + a - lo;
-                if (zz >= 0 && zz < 4) v += acc[zz >> 1][ni][((zz & 1) << 3) | (r & 7)];
+                if (zz >= 0 && zz < SR_) v += acc[zz >> 1][ni][((zz & 1) << 3) | (r & 7)];
               }
             } else {
               v = acc[mi][ni][r];
@@ -380,17 +381,19 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           }
       }
       __syncthreads();
-      pool_lines(SS, KK, nh);
+      pool_lines(SS, SRR, KK, nh);
       __syncthreads();
     };
-    auto pool_tile = [&](auto SS, auto KK) __attribute__((always_inline)) {
-      pool_half(std::integral_constant<int, 0>{}, SS, KK);
-      if constexpr (TN == 128) pool_half(std::integral_constant<int, 1>{}, SS, KK);
+    auto pool_tile = [&](auto SS, auto SRR, auto KK) __attribute__((always_inline)) {
+      pool_half(std::integral_constant<int, 0>{}, SS, SRR, KK);
+      if constexpr (TN == 128) pool_half(std::integral_constant<int, 1>{}, SS, SRR, KK);
     };
-    if (log2S == 3 && p.pool_k == 3) pool_tile(std::integral_constant<int, 8>{}, std::integral_constant<int, 3>{});
-    else if (log2S == 2 && p.pool_k == 2) pool_tile(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
-    else if (log2S == 2 && p.pool_k == 3) pool_tile(std::integral_constant<int, 4>{}, std::integral_constant<int, 3>{});
-    else if (log2S == 1 && p.pool_k == 2) pool_tile(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+    using std::integral_constant;
+    if (log2S == 3 && p.pool_k == 3) pool_tile(integral_constant<int, 8>{}, integral_constant<int, 8>{}, integral_constant<int, 3>{});
+    else if (log2S == 2 && p.pool_k == 2 && Sb == 3) pool_tile(integral_constant<int, 4>{}, integral_constant<int, 3>{}, integral_constant<int, 2>{});
+    else if (log2S == 2 && p.pool_k == 2) pool_tile(integral_constant<int, 4>{}, integral_constant<int, 4>{}, integral_constant<int, 2>{});
+    else if (log2S == 2 && p.pool_k == 3) pool_tile(integral_constant<int, 4>{}, integral_constant<int, 4>{}, integral_constant<int, 3>{});
+    else if (log2S == 1 && p.pool_k == 2) pool_tile(integral_constant<int, 2>{}, integral_constant<int, 2>{}, integral_constant<int, 2>{});
     return;
   }
 
@@ -544,6 +547,9 @@ int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream) {
   if (p.m_tiles <= 0 || p.n_tiles <= 0) return 0;
   if (p.pool_k > 1 && p.n_taps != 1) NESTI_FAIL("launch_conv: fused pooling needs a 1x1x1 layer");
   if (p.mp_mode != 0 && (p.log2S < 1 || !p.mp_out)) NESTI_FAIL("launch_conv: fused max-pool needs a volume >= 2^3 and an output");
+  if (p.s_real && !(p.s_real == 3 && p.log2S == 2)) NESTI_FAIL("launch_conv: s_real is the 3^3 grid inside a 4^3 index space only");
+  if (p.s_real && p.pool_k == 3) NESTI_FAIL("launch_conv: fused 3^3 avg-pool is not built for the embedded 3^3 volume");
+  if (p.s_real && p.mp_mode != 0) NESTI_FAIL("launch_conv: the fused 2^3 max-pool does not apply to the 3^3 volume");
   if (p.pool_k > 1 && !((p.log2S == 3 && p.pool_k == 3) || (p.log2S == 2 && (p.pool_k == 2 || p.pool_k == 3)) ||
                         (p.log2S == 1 && p.pool_k == 2)))
     NESTI_FAIL("launch_conv: fused pooling supports (S,k) in {(8,3),(4,3),(4,2),(2,2)}");

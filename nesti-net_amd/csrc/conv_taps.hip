@@ -58,7 +58,8 @@ __global__ __launch_bounds__(kThreads) void conv_taps_kernel(const ConvParams p)
   int npts = p.npoints;
   if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
   const int log2S = p.log2S, log2V = 3 * log2S;
-  const int S = 1 << log2S, V = 1 << log2V;
+  const int V = 1 << log2V;
+  const int S = p.s_real ? p.s_real : (1 << log2S);   // bounds only (rows are laid out in the 2^log2S index space)
   const long long total_rows = (long long)npts << log2V;
   const long long r0 = (long long)m_tile * kTileM;
   if (r0 >= total_rows) return;
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(kThreads) void conv_taps_kernel(const ConvParams p)
     off_l = (l32 >> 3) * 64 + yl * 4 + xl;
     key_mask = 1; key_hi = (l32 >> 3) << 1;     // swizzle key = ((row >> 1) & 1) | (point << 1)
   } else {                              // rows [32t, 32t+32)
-    const int lv = l32 & (V - 1);
-    zl = lv >> (2 * log2S); yl = (lv >> log2S) & (S - 1); xl = lv & (S - 1);
+    const int lv = l32 & (V - 1), Sm = (1 << log2S) - 1;
+    zl = lv >> (2 * log2S); yl = (lv >> log2S) & Sm; xl = lv & Sm;
     off_l = l32;
   }
   int base_t[8], zt[8], yt[8];
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void conv_taps_kernel(const ConvParams p)
     const int t = 8 * mh + i;
     if (remap && log2S == 3) { base_t[i] = 128 * (t >> 2) + 16 * (t & 3); zt[i] = 2 * (t >> 2); yt[i] = 2 * (t & 3); }
     else if (remap) { base_t[i] = 256 * (t >> 3) + 16 * ((t >> 1) & 3) + 8 * (t & 1); zt[i] = (t >> 1) & 3; yt[i] = 2 * (t & 1); }
-    else { const int tv = (32 * t) & (V - 1); base_t[i] = 32 * t; zt[i] = tv >> (2 * log2S); yt[i] = (tv >> log2S) & (S - 1); }
+    else { const int tv = (32 * t) & (V - 1); base_t[i] = 32 * t; zt[i] = tv >> (2 * log2S); yt[i] = (tv >> log2S) & ((1 << log2S) - 1); }
   }
 
   // ---- input chunk staging (as conv_igemm_kernel: wave w, piece j covers LDS rows (8w+j)*8 .. +8) ----------------
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void conv_taps_kernel(const ConvParams p)
   const int out_col0 = p.out_coff + n_tile * 128;
   const float bv = p.bias[n_tile * 128 + ng * 32 + l32];
   const float act_floor = p.relu ? 0.f : -INFINITY;
-  const int Vo = V >> 3, So = S >> 1, log2So = log2S - 1;
+  const int Vo = V >> 3, So = 1 << (log2S - 1), log2So = log2S - 1;
   auto cvt_store = [&](unsigned char* dst, const float4& v) __attribute__((always_inline)) {
     if (out_esz == 4) {
       *reinterpret_cast<float4*>(dst) = v;

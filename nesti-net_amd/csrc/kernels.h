@@ -26,7 +26,9 @@ struct ConvParams {
   int in_cstride, in_coff;
   int out_cstride, out_coff;
   int n_chunks, n_taps;
-  int log2S;           // S in {1,2,4,8}
+  int log2S;           // S in {1,2,4,8}: the index space rows are laid out in
+  int s_real;          // 0, or the real volume edge when it is smaller than S (3^3 Gaussian grid embedded in 4^3:
+                       // voxels with a coordinate >= s_real are dead rows -- never read as neighbours, contents ignored)
   int relu, out_f32;
   int m_tiles, n_tiles;
   // merged inception conv1|conv4 launch: column tiles >= split_tile are conv4's; they write at
@@ -60,6 +62,9 @@ struct PoolParams {
   int log2S;           // input S
 };
 int launch_maxpool2(const PoolParams& p, int dtype, hipStream_t stream);
+// tf.nn.max_pool3d [3,3,3] stride 2 SAME on a 3^3 volume (models/experts_n_est.py:238): input rows in the 4^3-embedded
+// layout (log2S = 2), output 2^3 (8 rows per point); output cell o covers input {o, o+1} per axis.
+int launch_maxpool3s2(const PoolParams& p, int dtype, hipStream_t stream);
 
 // softmax over the first E logits of each row + first-index arg-max
 // (models/experts_n_est.py:177, test_n_est_w_experts.py:150); optional routing lists.

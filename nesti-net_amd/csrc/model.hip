@@ -92,7 +92,8 @@ struct LayerDesc {
   int pool_k = 1;            // avg-pool window applied to scope2's pre-activation (conv4 of an inception)
   bool is_fc = false;
   int k = 1;                 // kernel size (1 for fc)
-  int log2S = 0;             // spatial size the layer runs at
+  int log2S = 0;             // spatial index space the layer runs at
+  int s_real = 0;            // 3: the 3^3 Gaussian grid embedded in the 4^3 index space (0: the volume is 2^log2S)
   int cin = 0, cout = 0;     // real channel counts (TF variable shapes); scope2 has the same shape
   std::vector<int> in_pos;   // real input channel -> position inside the padded input slice
   int Cin_p = 0, Cout_p = 0;
@@ -102,7 +103,7 @@ struct LayerDesc {
 struct BufSpec { int log2S; int C; bool f32; };
 
 struct Op {
-  enum Kind { CONV, MAX } kind;
+  enum Kind { CONV, MAX, MAX3 } kind;   // MAX3: max_pool3d [3,3,3] stride 2 SAME, 3^3 (embedded) -> 2^3
   int in_buf = 0, in_coff = 0, out_buf = 0, out_coff = 0, out_coff2 = 0;
   int in_cstride = 0;          // 0: the input buffer's channel count; else a flattened view (FC on S^3 x C)
   int mp_buf = -1, mp_mode = 0; // fused 2^3 max-pool of the first tile group into this buffer (1: pooled only, 2: both)
@@ -122,6 +123,7 @@ struct ChanMap { std::vector<int> pos; int C = 0; };   // real channel -> padded
 
 struct Graph {
   nesti_config_t cfg;
+  int gate_x0_log2S() const { return cfg.grid_n == 3 ? 2 : 3; }   // index space of the MuPS rows of one point
   int mups_cstride = 64;
   std::vector<LayerDesc> layers;
   Tower gate;
@@ -130,6 +132,7 @@ struct Graph {
 
 struct Builder {
   Graph& g;
+  int s_real = 0;            // stamped on the layers built while it is set (conv_net_3g)
   explicit Builder(Graph& gg) : g(gg) {}
 
   int add_layer(const LayerDesc& d) { g.layers.push_back(d); return (int)g.layers.size() - 1; }
@@ -139,6 +142,7 @@ struct Builder {
            const std::string& scope2 = "", int out_coff2 = 0, int pool_k = 1) {
     LayerDesc d;
     d.scope = scope; d.scope2 = scope2; d.pool_k = pool_k; d.is_fc = fc; d.k = k; d.log2S = log2S;
+    d.s_real = fc ? 0 : s_real;
     d.cin = (int)in.pos.size(); d.cout = cout; d.in_pos = in.pos; d.Cin_p = in.C;
     d.Cout_p = pad_to(cout, kPad) * (scope2.empty() ? 1 : 2); d.bn = bn; d.relu = relu;
     Op op; op.kind = Op::CONV; op.in_buf = in_buf; op.in_coff = in_coff; op.out_buf = out_buf; op.out_coff = out_coff;
@@ -211,7 +215,28 @@ struct Builder {
 
   void init_tower(Tower& T) {
     T.bufs.clear(); T.ops.clear();
-    T.bufs.push_back({3, g.mups_cstride, false});   // 0: X0
+    T.bufs.push_back({g.cfg.grid_n == 3 ? 2 : 3, g.mups_cstride, false});   // 0: X0 (3^3 grid: rows in a 4^3 index space)
+  }
+
+  // conv_net_3g (models/experts_n_est.py:217-240): four inception blocks on the 3^3 grid (kernel sizes [2,3], [2,3],
+  // [1,2], [1,2]; k0 = 1 makes conv2 a 1x1x1 layer and the avg-pool of the conv4 branch the identity), then
+  // max_pool3d [3,3,3] stride 2 SAME -> 2^3 x 1536, flattened voxel-major.  The 27 voxels live in a 4^3 index space
+  // (kernels.h: ConvParams::s_real).  Returns the pooled buffer; *flat describes it as one FC input row.
+  int conv_net_3g(Tower& T, const std::string& s, ChanMap m, ChanMap* flat) {
+    s_real = 3;
+    int b = inception(T, "inception1" + s, 0, m, 128, 2, 3, 2, &m);
+    b = inception(T, "inception2" + s, b, m, 256, 2, 3, 2, &m);
+    b = inception(T, "inception3" + s, b, m, 256, 1, 2, 2, &m);
+    b = inception(T, "inception4" + s, b, m, 512, 1, 2, 2, &m);
+    s_real = 0;
+    T.bufs.push_back({1, m.C, false});
+    const int pb = (int)T.bufs.size() - 1;
+    Op op; op.kind = Op::MAX3; op.in_buf = b; op.out_buf = pb; op.in_coff = op.out_coff = 0; op.C = m.C; op.log2S = 2;
+    T.ops.push_back(op);                                                    // maxpool5  :238
+    flat->pos.clear(); flat->C = 8 * m.C;
+    for (int v = 0; v < 8; ++v)
+      for (size_t c = 0; c < m.pos.size(); ++c) flat->pos.push_back(v * m.C + m.pos[c]);
+    return pb;
   }
 
   // scale_manager_net + conv_net_8g (models/experts_n_est.py:155-215)
@@ -222,6 +247,14 @@ struct Builder {
     ChanMap m; m.C = g.mups_cstride;
     for (int c = 0; c < 20 * S; ++c) m.pos.push_back(c);
     const std::string s = "gating_conv";
+    if (g.cfg.grid_n == 3) {   // models/experts_n_est.py:162-163
+      ChanMap flat;
+      const int pb = conv_net_3g(T, s, m, &flat);
+      T.out_buf = fc_stack(T, pb, flat, {"fc1noise", "fc2noise", "fc3noise", "fc4noise"}, {1024, 256, 128, g.cfg.n_experts},
+                           /*last_relu=*/true, flat.C);
+      T.n_out = g.cfg.n_experts;
+      return;
+    }
     int b = inception(T, "inception1" + s, 0, m, 128, 3, 5, 3, &m);
     b = inception(T, "inception2" + s, b, m, 256, 3, 5, 3, &m);
     b = inception(T, "inception3" + s, b, m, 256, 3, 5, 3, &m, true);    // + maxpool4  :198
@@ -287,6 +320,13 @@ struct Builder {
     ChanMap m; m.C = g.mups_cstride;
     for (int c = 0; c < 20 * cnt; ++c) m.pos.push_back(20 * lo + c);   // MuPS[..., start:end]  :100-102
     const std::string s = "Expert_" + std::to_string(i);
+    if (g.cfg.grid_n == 3) {   // models/experts_n_est.py:275-276: the 3^3 branch ignores `divider`
+      ChanMap flat;
+      const int pb = conv_net_3g(T, s + "_expert_conv", m, &flat);
+      T.out_buf = fc_stack(T, pb, flat, {"fc1" + s, "fc2" + s, "fc3" + s, "fc4" + s}, {512, 128, 64, 3}, /*last_relu=*/false, flat.C);
+      T.n_out = 3;
+      return;
+    }
     const int F1 = 128 / cnt;   // np.round(128 / divider) under Python-2 integer division  :254
     int b = inception(T, "inception1" + s, 0, m, F1, 3, 5, 3, &m);
     b = inception(T, "inception2" + s, b, m, 256, 3, 5, 3, &m, true);    // + maxpool3  :261
@@ -304,7 +344,9 @@ int build_graph(const nesti_config_t* cfg, Graph* g) {
   if (cfg->arch == NESTI_ARCH_SWITCH && cfg->n_scales != 2)
     NESTI_FAIL("NESTI_ARCH_SWITCH (ms_sw_n_est) takes exactly two scales (models/ms_sw_n_est.py:50)");
   if (cfg->arch == NESTI_ARCH_SINGLE && cfg->n_scales != 1) NESTI_FAIL("NESTI_ARCH_SINGLE (ss_norm_est) takes exactly one scale");
-  if (cfg->grid_n != 8) NESTI_FAIL("only the 8^3 Gaussian grid is implemented");
+  if (cfg->grid_n != 8 && !(cfg->grid_n == 3 && cfg->arch == NESTI_ARCH_EXPERTS))
+    NESTI_FAIL("the Gaussian grid must be 8^3 (any model) or 3^3 (experts_n_est only: the ablation models are 8^3-only, "
+               "models/ms_sw_n_est.py:183)");
   if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("bad n_scales");
   if (cfg->n_experts < 1 || cfg->n_experts > NESTI_MAX_EXPERTS) NESTI_FAIL("bad n_experts");
   for (int i = 0; i < cfg->n_experts && cfg->arch == NESTI_ARCH_EXPERTS; ++i) {
@@ -440,7 +482,7 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
   if (fold_layer(d, d.scope, tt, &parts[0])) return 1;
   if (n_parts == 2 && fold_layer(d, d.scope2, tt, &parts[1])) return 1;
   const int part_p = d.Cout_p / n_parts;   // padded width of one part
-  const int S = 1 << d.log2S;
+  const int S = d.s_real ? d.s_real : (1 << d.log2S);
   const int lo = (d.k - 1) / 2;   // TF SAME, stride 1
   pl->n_taps = 0;
   std::vector<int> tap_widx;
@@ -564,7 +606,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.npoints = rc.NB;
       p.in_cstride = op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
       p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
-      p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S;
+      p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S; p.s_real = d.s_real;
       p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
       const long long rows = (long long)rc.NB << (3 * d.log2S);
       p.m_tiles = (int)((rows + kTileM - 1) / kTileM);
@@ -586,7 +628,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
       p.C = op.C; p.log2S = op.log2S;
       prof_begin(NESTI_PROF_POOL, rc.stream);
-      const int rcp = launch_maxpool2(p, dtype, rc.stream);
+      const int rcp = op.kind == Op::MAX3 ? launch_maxpool3s2(p, dtype, rc.stream) : launch_maxpool2(p, dtype, rc.stream);
       prof_end(NESTI_PROF_POOL, rc.stream);
       if (rcp) return 1;
     }
@@ -606,7 +648,7 @@ struct WsLayout {
 };
 WsLayout ws_layout(const nesti_model* m, int NB) {
   WsLayout L;
-  const size_t act = align_up(((size_t)NB << 9) * m->graph.mups_cstride * dtype_size(m->dtype), 256);
+  const size_t act = align_up(((size_t)NB << (3 * m->graph.gate_x0_log2S())) * m->graph.mups_cstride * dtype_size(m->dtype), 256);
   size_t o = 0;
   L.x0 = o; o += act;
   L.probs = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
@@ -700,7 +742,7 @@ int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev, const
   if (B <= 0) return 0;   // empty batch: nothing to do
   if (!cfg || !points_dev || !n_eff_dev || !out_dev) NESTI_FAIL("nesti_mups_forward: null argument");
   prof_begin(NESTI_PROF_MUPS, (hipStream_t)stream);
-  const int rc = launch_mups(cfg, points_dev, n_eff_dev, B, out_dev, out_dtype, out_cstride, (hipStream_t)stream);
+  const int rc = launch_mups(cfg, points_dev, n_eff_dev, B, out_dev, out_dtype, out_cstride, /*embed4=*/0, (hipStream_t)stream);
   prof_end(NESTI_PROF_MUPS, (hipStream_t)stream);
   return rc;
 }
@@ -752,6 +794,18 @@ size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch) {
 }
 
 int nesti_model_mups_cstride(const nesti_model_t* m) { return m ? m->graph.mups_cstride : 0; }
+int nesti_model_mups_rows(const nesti_model_t* m) { return m ? 1 << (3 * m->graph.gate_x0_log2S()) : 0; }
+
+int nesti_model_mups(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B, void* mups_out_dev,
+                     void* stream) {
+  if (B <= 0) return 0;
+  if (!m || !points_dev || !n_eff_dev || !mups_out_dev) NESTI_FAIL("nesti_model_mups: null argument");
+  prof_begin(NESTI_PROF_MUPS, (hipStream_t)stream);
+  const int rc = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, mups_out_dev, m->dtype, m->graph.mups_cstride,
+                             /*embed4=*/m->graph.cfg.grid_n == 3, (hipStream_t)stream);
+  prof_end(NESTI_PROF_MUPS, (hipStream_t)stream);
+  return rc;
+}
 
 int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void* ws_dev, size_t ws_bytes,
                        float* probs_out_dev, int32_t* expert_out_dev, void* stream) {
@@ -798,7 +852,8 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   hipStream_t st = (hipStream_t)stream;
   void* X0 = ws + L.x0;
   prof_begin(NESTI_PROF_MUPS, st);
-  const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride, st);
+  const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride,
+                              /*embed4=*/m->graph.cfg.grid_n == 3, st);
   prof_end(NESTI_PROF_MUPS, st);
   if (rcm) return 1;
   if (m->graph.cfg.arch == NESTI_ARCH_SINGLE || m->graph.cfg.arch == NESTI_ARCH_MULTI)   // single-tower ablations: the tower's output IS n_pred (test_n_est.py:136-141)
@@ -837,7 +892,7 @@ int nesti_model_macs(const nesti_model_t* m, int tower, double* nominal, double*
     if (op.kind != Op::CONV) continue;
     const LayerDesc& d = m->graph.layers[op.layer];
     const PackedLayer& pl = m->packed[op.layer];
-    const int S = 1 << d.log2S, V = S * S * S, lo = (d.k - 1) / 2;
+    const int S = d.s_real ? d.s_real : (1 << d.log2S), V = S * S * S, lo = (d.k - 1) / 2;
     long long valid = 0;   // sum over output voxels of the taps that land inside the volume
     for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)
       for (int a = 0; a < d.k; ++a) for (int b = 0; b < d.k; ++b) for (int c = 0; c < d.k; ++c) {
@@ -847,7 +902,7 @@ int nesti_model_macs(const nesti_model_t* m, int tower, double* nominal, double*
     const int parts = d.scope2.empty() ? 1 : 2;
     nom += (double)parts * V * d.k * d.k * d.k * d.cin * d.cout;
     use += (double)parts * valid * d.cin * d.cout;
-    iss += (double)V * pl.n_taps * d.Cin_p * d.Cout_p;
+    iss += (double)(1 << (3 * d.log2S)) * pl.n_taps * d.Cin_p * d.Cout_p;
   }
   if (nominal) *nominal = nom;
   if (useful) *useful = use;

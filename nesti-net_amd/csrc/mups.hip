@@ -280,34 +280,143 @@ __global__ __launch_bounds__(kThreads) void mups_kernel(const float* __restrict_
   }
 }
 
+// ---- 3^3 Gaussian grid (27 Gaussians, --num_gaussians 3: the reference's training default, train_n_est_w_experts.py:55)
+// The same arithmetic on a small grid: one 64-thread workgroup per query, thread g < 27 owns Gaussian
+// g = 9 i + 3 j + k; 64 patch points at a time are expanded into per-axis (q, d, d^2-1) terms in LDS.  Output rows:
+// dense [B, 27, cstride] or, for the convolution towers, embedded in a 4^3 index space [B, 64, cstride] with row
+// 16 i + 4 j + k (rows with a coordinate of 3 are written as zeros).
+template <int DT>
+__global__ __launch_bounds__(64) void mups3_kernel(const float* __restrict__ points, const int32_t* __restrict__ n_eff,
+                                                   int B, int S, int P, void* __restrict__ out, int cstride,
+                                                   float sigma, float w, float mu0, float mu1, float mu2, int embed) {
+  __shared__ float4 stage[64][9];     // [point][3 * axis + grid index] = {q, d, d^2 - 1, -}
+  __shared__ float norm2[20];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const bool own = t < 27;
+  const int gi = t / 9, gj = (t / 3) % 3, gk = t % 3;
+  const int rows_pp = embed ? 64 : 27;
+  const int row = embed ? 16 * gi + 4 * gj + gk : t;
+  using E = Elem<DT>;
+  typename E::T* o = reinterpret_cast<typename E::T*>(out);
+  const float mus[3] = {mu0, mu1, mu2};
+  for (int s = 0; s < S; ++s) {
+    const int m = n_eff[(size_t)b * S + s];
+    const size_t o0 = ((size_t)b * rows_pp + row) * cstride + 20 * s;
+    float v[20];
+    if (m <= 0) {     // zero-padded batch tail: skip, do not divide by 0
+#pragma unroll
+      for (int c = 0; c < 20; ++c) v[c] = 0.f;
+      if (own) store20<DT>(out, o0, v);
+      continue;
+    }
+    const int nrows = min(m + 1, P);               // mask = r > n_eff (utils/tf_util.py:693)
+    const bool has_masked = nrows < P;
+    const float* pts = points + ((size_t)b * S + s) * (size_t)P * 3;
+    Stats1 st;
+    st.sq = 0.f; st.mq = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      st.mu_max[c] = -INFINITY; st.mu_min[c] = INFINITY; st.mu_sum[c] = 0.f;
+      st.sg_max[c] = -INFINITY; st.sg_min[c] = INFINITY; st.sg_sum[c] = 0.f;
+    }
+    for (int c0 = 0; c0 < nrows; c0 += 64) {
+      __syncthreads();
+      if (c0 + t < nrows) {
+#pragma unroll
+        for (int axis = 0; axis < 3; ++axis) {
+          const float x = pts[(size_t)(c0 + t) * 3 + axis];
+          float d[3], e[3], sum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            d[i] = (x - mus[i]) / sigma;                       // utils/tf_util.py:687
+            e[i] = expf(-0.5f * d[i] * d[i]);
+            sum += e[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i) stage[t][3 * axis + i] = make_float4(e[i] / sum, d[i], d[i] * d[i] - 1.0f, 0.f);
+        }
+      }
+      __syncthreads();
+      const int cnt = min(64, nrows - c0);
+      if (own) {
+        for (int nl = 0; nl < cnt; ++nl) {
+          const float4 X = stage[nl][gi], Y = stage[nl][3 + gj], Z = stage[nl][6 + gk];
+          const float Q = X.x * (Y.x * Z.x);
+          const float d[3] = {X.y, Y.y, Z.y}, e[3] = {X.z, Y.z, Z.z};
+          st.sq += Q;
+          st.mq = fmaxf(st.mq, Q);
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float mm = Q * d[c], vv = Q * e[c];
+            st.mu_max[c] = fmaxf(st.mu_max[c], mm); st.mu_min[c] = fminf(st.mu_min[c], mm); st.mu_sum[c] += mm;
+            st.sg_max[c] = fmaxf(st.sg_max[c], vv); st.sg_min[c] = fminf(st.sg_min[c], vv); st.sg_sum[c] += vv;
+          }
+        }
+      }
+    }
+    if (own) finish(st, nrows, has_masked, (float)m, w, v);
+    else {
+#pragma unroll
+      for (int c = 0; c < 20; ++c) v[c] = 0.f;
+    }
+    // L2 normalisation over the 27 Gaussians, per channel (utils/tf_util.py:738-740)
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 20; ++c) {
+      float p2 = v[c] * v[c];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) p2 += __shfl_xor(p2, off, 64);
+      if (t == 0) norm2[c] = p2;
+    }
+    __syncthreads();
+    if (own) {
+#pragma unroll
+      for (int c = 0; c < 20; ++c) v[c] *= 1.0f / sqrtf(fmaxf(norm2[c], 1e-12f));
+      store20<DT>(out, o0, v);
+    }
+  }
+  // padding channels [20 S, cstride) of the owned rows, and (embedded layout) the whole dead rows: zeros
+  for (int r = t; r < rows_pp; r += 64) {
+    const bool dead = embed && (((r >> 4) & 3) == 3 || ((r >> 2) & 3) == 3 || (r & 3) == 3);
+    for (int c = dead ? 0 : 20 * S; c < cstride; ++c) o[((size_t)b * rows_pp + r) * cstride + c] = E::from_f32(0.f);
+  }
+}
+
 }  // namespace
 
 int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n_eff, int B,
-                void* out, int out_dtype, int out_cstride, hipStream_t stream) {
-  if (cfg->grid_n != kR) NESTI_FAIL("nesti_mups_forward: only the 8^3 Gaussian grid is implemented");
+                void* out, int out_dtype, int out_cstride, int embed4, hipStream_t stream) {
+  if (cfg->grid_n != kR && cfg->grid_n != 3) NESTI_FAIL("nesti_mups_forward: the Gaussian grid must be 8^3 or 3^3");
   if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("nesti_mups_forward: bad n_scales");
   if (out_cstride < 20 * cfg->n_scales || (out_cstride % 4) != 0)
     NESTI_FAIL("nesti_mups_forward: out_cstride must be >= 20*S and a multiple of 4");
+  if (out_dtype != NESTI_F32 && out_dtype != NESTI_BF16 && out_dtype != NESTI_F16) NESTI_FAIL("nesti_mups_forward: unknown out_dtype");
   if (B <= 0) return 0;
   const float sigma = (float)sqrt(cfg->variance);     // np.sqrt in f64, then the f32 placeholder: test_n_est_w_experts.py:146
+  const int S = cfg->n_scales, P = cfg->points_per_scale;
+  if (cfg->grid_n == 3) {
+    const float w = (float)(1.0 / 27.0);
+    // np.mgrid[1/3 - 1 : 1 - 1/3 : 3j] in f64, fed through the f32 placeholder (utils/utils.py:81-87)
+    const double a0 = 1.0 / 3 - 1.0, a1 = 1.0 - 1.0 / 3;
+    const float mu0 = (float)a0, mu1 = (float)(a0 + (a1 - a0) * 1 / 2.0), mu2 = (float)(a0 + (a1 - a0) * 2 / 2.0);
+    dim3 grid(B), block(64);
+    if (out_dtype == NESTI_F32)
+      hipLaunchKernelGGL(mups3_kernel<NESTI_F32>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w, mu0, mu1, mu2, embed4);
+    else if (out_dtype == NESTI_BF16)
+      hipLaunchKernelGGL(mups3_kernel<NESTI_BF16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w, mu0, mu1, mu2, embed4);
+    else
+      hipLaunchKernelGGL(mups3_kernel<NESTI_F16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w, mu0, mu1, mu2, embed4);
+    NESTI_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const float w = 1.0f / (float)kG;                  // utils/utils.py:89
   dim3 grid(B), block(kThreads);
-  switch (out_dtype) {
-    case NESTI_F32:
-      hipLaunchKernelGGL(mups_kernel<NESTI_F32>, grid, block, 0, stream, points, n_eff, B,
-                         cfg->n_scales, cfg->points_per_scale, out, out_cstride, sigma, w);
-      break;
-    case NESTI_BF16:
-      hipLaunchKernelGGL(mups_kernel<NESTI_BF16>, grid, block, 0, stream, points, n_eff, B,
-                         cfg->n_scales, cfg->points_per_scale, out, out_cstride, sigma, w);
-      break;
-    case NESTI_F16:
-      hipLaunchKernelGGL(mups_kernel<NESTI_F16>, grid, block, 0, stream, points, n_eff, B,
-                         cfg->n_scales, cfg->points_per_scale, out, out_cstride, sigma, w);
-      break;
-    default:
-      NESTI_FAIL("nesti_mups_forward: unknown out_dtype");
-  }
+  if (out_dtype == NESTI_F32)
+    hipLaunchKernelGGL(mups_kernel<NESTI_F32>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w);
+  else if (out_dtype == NESTI_BF16)
+    hipLaunchKernelGGL(mups_kernel<NESTI_BF16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w);
+  else
+    hipLaunchKernelGGL(mups_kernel<NESTI_F16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

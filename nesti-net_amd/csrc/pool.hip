@@ -75,6 +75,42 @@ __global__ __launch_bounds__(kThreads) void maxpool2_kernel(const PoolParams p) 
   }
 }
 
+// tf.nn.max_pool3d(k=[3,3,3], stride 2, SAME) on a 3^3 volume (conv_net_3g, models/experts_n_est.py:238): TF pads one
+// voxel in front, so output cell o reads input {2o-1, 2o, 2o+1} clipped to [0,2] = {o, o+1} per axis.  Input rows live
+// in the 4^3 index space (row 16 z + 4 y + x), output is a dense 2^3.
+template <int DT>
+__global__ __launch_bounds__(kThreads) void maxpool3s2_kernel(const PoolParams p) {
+  using V = Vec16<DT>;
+  constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
+  int npts = p.npoints;
+  if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
+  const int nv = p.C / V::N;
+  const long long total = (long long)npts * 8 * nv;
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in);
+  unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % nv);
+    const long long orow = idx / nv;
+    const long long pt = orow >> 3;
+    const int cell = (int)(orow & 7);
+    const int z = cell >> 2, y = (cell >> 1) & 1, x = cell & 1;
+    float m[V::N];
+#pragma unroll
+    for (int e = 0; e < V::N; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      const int zz = z + (a >> 2), yy = y + ((a >> 1) & 1), xx = x + (a & 1);
+      const long long srow = pt * 64 + zz * 16 + yy * 4 + xx;
+      const uint4 v = *reinterpret_cast<const uint4*>(in_b + (srow * p.in_cstride + p.in_coff) * kEsz + cv * 16);
+      float f[V::N];
+      V::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < V::N; ++e) m[e] = fmaxf(m[e], f[e]);
+    }
+    *reinterpret_cast<uint4*>(out_b + (orow * p.out_cstride + p.out_coff) * kEsz + cv * 16) = V::pack(m);
+  }
+}
+
 // softmax (models/experts_n_est.py:177) + np.argmax first-index tie-break
 // (test_n_est_w_experts.py:150) + optional routing lists for top-1 execution.
 __global__ void gate_finish_kernel(const float* __restrict__ logits, int lstride, int B, int E,
@@ -156,6 +192,19 @@ int launch_maxpool2(const PoolParams& p, int dtype, hipStream_t stream) {
   if (dtype == NESTI_F32) hipLaunchKernelGGL(maxpool2_kernel<NESTI_F32>, grid, block, 0, stream, p);
   else if (dtype == NESTI_BF16) hipLaunchKernelGGL(maxpool2_kernel<NESTI_BF16>, grid, block, 0, stream, p);
   else hipLaunchKernelGGL(maxpool2_kernel<NESTI_F16>, grid, block, 0, stream, p);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_maxpool3s2(const PoolParams& p, int dtype, hipStream_t stream) {
+  if (p.npoints <= 0) return 0;
+  const int n = (dtype == NESTI_F32) ? 4 : 8;
+  if (p.C % n) NESTI_FAIL("maxpool3s2: C must be a multiple of the 16-byte vector");
+  const long long work = (long long)p.npoints * 8 * (p.C / n);
+  dim3 grid(grid_for(work)), block(kThreads);
+  if (dtype == NESTI_F32) hipLaunchKernelGGL(maxpool3s2_kernel<NESTI_F32>, grid, block, 0, stream, p);
+  else if (dtype == NESTI_BF16) hipLaunchKernelGGL(maxpool3s2_kernel<NESTI_BF16>, grid, block, 0, stream, p);
+  else hipLaunchKernelGGL(maxpool3s2_kernel<NESTI_F16>, grid, block, 0, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

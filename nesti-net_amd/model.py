@@ -122,8 +122,20 @@ class NestiNet:
 
     # -- pieces (tests and the reference-shaped API) ---------------------------------------
     def mups(self, points, n_eff, stream=None):
-        """MuPS in the model's internal layout [B, R^3... , cstride] / dtype."""
-        return mups_forward(self.cfg, points, n_eff, out_dtype=self.dtype, out_cstride=self.mups_cstride, stream=stream)
+        """MuPS in the layout / dtype the towers read (``nesti_model_mups``): [B, Ri, Ri, Ri, cstride] with
+        Ri = 8, or Ri = 4 for the 3^3 grid (the 27 voxels sit at [:, :3, :3, :3], the rest is zero)."""
+        B = points.shape[0]
+        S, P = self.cfg.n_scales, self.cfg.num_point
+        if tuple(points.shape) != (B, S * P, 3):
+            raise ValueError("points must be [B, %d, 3], got %s" % (S * P, tuple(points.shape)))
+        points = points.contiguous().float()
+        n_eff_i = n_eff.to(device=points.device, dtype=torch.int32).contiguous().view(B, S)
+        Ri = round(self.lib.nesti_model_mups_rows(self._handle) ** (1.0 / 3.0))
+        out = torch.empty((B, Ri, Ri, Ri, self.mups_cstride), dtype=_TORCH_DT[self.dtype], device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_model_mups(self._handle, _lib.ptr(points), _lib.ptr(n_eff_i), B, _lib.ptr(out),
+                                                 self._stream(stream)), "nesti_model_mups")
+        return out
 
     def gate(self, mups, stream=None):
         """``scale_manager_net`` + arg-max -> (probs [B,E] f32, expert [B] int32); for ms_sw_n_est
@@ -211,5 +223,5 @@ def get_model(net: NestiNet, points, original_n_points):
     mups = net.mups(points, original_n_points)
     probs, _ = net.gate(mups)
     n_est = net.experts(mups, None)
-    S = net.cfg.n_scales
-    return probs.t().contiguous(), n_est, mups[..., :20 * S].float()
+    S, R = net.cfg.n_scales, net.cfg.n_gaussians
+    return probs.t().contiguous(), n_est, mups[:, :R, :R, :R, :20 * S].float()

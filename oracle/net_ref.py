@@ -92,11 +92,35 @@ def inception(x, W, scope, k0, k1, dtype):
     return torch.cat([c1, c2, c3, c4], dim=4)
 
 
+def max_pool3d_3s2_same(x):
+    """``tf.nn.max_pool3d`` [3,3,3] stride 2 SAME (``models/experts_n_est.py:238``): out = ceil(in/2); for in = 3
+    TF pads one voxel on each side (ignored by the max), i.e. torch's padding=1 with -inf."""
+    assert x.shape[1] == x.shape[2] == x.shape[3] == 3
+    return F.max_pool3d(x.permute(0, 4, 1, 2, 3), 3, 2, padding=1).permute(0, 2, 3, 4, 1)
+
+
+def conv_net_3g(x, W, s, dtype):
+    """``conv_net_3g`` (``models/experts_n_est.py:217-240``): [B,3,3,3,C] -> [B, 2*2*2*1536]."""
+    x = inception(x, W, "inception1" + s, 2, 3, dtype)
+    x = inception(x, W, "inception2" + s, 2, 3, dtype)
+    x = inception(x, W, "inception3" + s, 1, 2, dtype)
+    x = inception(x, W, "inception4" + s, 1, 2, dtype)
+    x = max_pool3d_3s2_same(x)
+    return x.reshape(x.shape[0], -1)
+
+
 def gate_forward(mups, W, dtype=torch.float64):
-    """``scale_manager_net`` + ``conv_net_8g`` (``models/experts_n_est.py:155-215``).
+    """``scale_manager_net`` + ``conv_net_8g`` / ``conv_net_3g`` (``models/experts_n_est.py:155-240``).
     Returns (probs [B,E], logits-after-relu [B,E])."""
     s = "gating_conv"
     x = _t(mups, dtype)
+    if x.shape[1] == 3:                                                # 27 Gaussians  :162-163
+        g = conv_net_3g(x, W, s, dtype)
+        g = fc(g, W, "fc1noise", dtype)
+        g = fc(g, W, "fc2noise", dtype)
+        g = fc(g, W, "fc3noise", dtype)
+        logits = fc(g, W, "fc4noise", dtype, bn=False, relu=True)
+        return torch.softmax(logits, dim=1), logits
     x = inception(x, W, "inception1" + s, 3, 5, dtype)
     x = inception(x, W, "inception2" + s, 3, 5, dtype)
     x = inception(x, W, "inception3" + s, 3, 5, dtype)
@@ -118,6 +142,12 @@ def expert_forward(mups_slice, W, i, dtype=torch.float64):
     """``normal_est_net`` 8^3 branch (``models/experts_n_est.py:243-291``)."""
     s = "Expert_%d" % i
     x = _t(mups_slice, dtype)
+    if x.shape[1] == 3:                                                # :275-276 (`divider` unused on this branch)
+        g = conv_net_3g(x, W, s + "_expert_conv", dtype)
+        g = fc(g, W, "fc1" + s, dtype)
+        g = fc(g, W, "fc2" + s, dtype)
+        g = fc(g, W, "fc3" + s, dtype)
+        return fc(g, W, "fc4" + s, dtype, bn=False, relu=False)
     x = inception(x, W, "inception1" + s, 3, 5, dtype)
     x = inception(x, W, "inception2" + s, 3, 5, dtype)
     x = max_pool3d_2(x)

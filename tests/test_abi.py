@@ -98,10 +98,33 @@ def test_config_expert_dict_and_errors():
     assert NestiConfig(expert_dict=None).default_expert_dict() == {0: [0], 1: [0], 2: [1], 3: [1], 4: [2], 5: [2],
                                                                     6: [0, 1, 2]}
     lib = _lib.load()
-    bad = NestiConfig(n_gaussians=3).to_c()
+    bad = NestiConfig(n_gaussians=5).to_c()
     n = ctypes.c_int(0)
     assert lib.nesti_model_describe(ctypes.byref(bad), ctypes.byref(n), None, 0) != 0
     assert b"8^3" in lib.nesti_last_error()
+    bad = NestiConfig.for_model("ss_norm_est")
+    bad.n_gaussians = 3                      # the ablation models exist for the 8^3 grid only
+    c = bad.to_c()
+    assert lib.nesti_model_describe(ctypes.byref(c), ctypes.byref(n), None, 0) != 0
+
+
+def test_describe_3_gaussian_grid_graph():
+    """--num_gaussians 3 (27 Gaussians): conv_net_3g for the gate and every expert (models/experts_n_est.py:162-163,
+    217-240, 275-276); the expert towers carry the '_expert_conv' scope suffix and ignore the filter divider."""
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import NestiConfig
+    d = weights.describe(NestiConfig(n_gaussians=3, gmm_variance=0.111))
+    assert d["inception1gating_conv_conv1/weights"] == (1, 1, 1, 60, 128)
+    assert d["inception1gating_conv_conv2/weights"] == (2, 2, 2, 128, 64)
+    assert d["inception2gating_conv_conv3/weights"] == (3, 3, 3, 256, 128)
+    assert d["inception3gating_conv_conv2/weights"] == (1, 1, 1, 256, 128)
+    assert d["inception4gating_conv_conv3/weights"] == (2, 2, 2, 512, 256)
+    assert d["fc1noise/weights"] == (12288, 1024) and d["fc4noise/weights"] == (128, 7)
+    assert d["inception1Expert_6_expert_conv_conv1/weights"] == (1, 1, 1, 60, 128)     # no divider on this branch
+    assert d["inception1Expert_2_expert_conv_conv1/weights"] == (1, 1, 1, 20, 128)
+    assert d["fc1Expert_2/weights"] == (12288, 512) and d["fc4Expert_2/weights"] == (64, 3)
+    assert not any(k.startswith("inception5") for k in d)
 
 
 def test_weight_container_roundtrip(tmp_path):

@@ -285,6 +285,52 @@ def test_switching_model_matches_oracle(gpu_device):
     assert np.all(same | (margin < 5e-3))
 
 
+def test_3_gaussian_grid_model_matches_oracle(gpu_device):
+    """--num_gaussians 3 (the reference's training default, train_n_est_w_experts.py:55-56): 27-Gaussian MuPS,
+    conv_net_3g towers (k = 2 / 3 / 1 on a 3^3 volume, max-pool [3,3,3]/2) for the gate and the 7 experts."""
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet, get_model, mups_forward
+    from oracle import mups_ref, net_ref
+    cfg = NestiConfig(n_gaussians=3, gmm_variance=0.111)
+    W = weights.synthetic_weights(cfg)
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid20k" in p][0])
+    B = 9
+    pts, n_eff = g["points"][:B], g["n_eff"][:B]
+    p_d, n_d = torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device)
+    mups_o = mups_ref.mups_assemble(pts, n_eff, 3, grid_n=3, variance=0.111)
+    # MuPS: dense [B,3,3,3,60] through the public entry point, and the towers' 4^3-embedded layout
+    dense = mups_forward(cfg, p_d, n_d, out_dtype="f32").cpu().numpy()
+    assert dense.shape == (B, 3, 3, 3, 60)
+    assert np.abs(dense - mups_o).max() < 2e-5
+    net = NestiNet(cfg, W, dtype="f32", device=gpu_device, max_batch=B)
+    emb = net.mups(p_d, n_d)
+    assert emb.shape == (B, 4, 4, 4, 64)
+    e = emb.cpu().numpy()
+    assert np.array_equal(e[:, :3, :3, :3, :60], dense)
+    assert not e[:, 3].any() and not e[:, :, 3].any() and not e[:, :, :, 3].any() and not e[..., 60:].any()
+    ref = net_ref.moe_forward(mups_o, W, dtype=torch.float64, top1_only=False)
+    probs, expert = net.gate(emb)
+    assert np.abs(probs.cpu().numpy() - ref["probs"].numpy()).max() < PROB_TOL_F32
+    assert np.array_equal(expert.cpu().numpy(), ref["expert"].numpy())
+    n_est = net.experts(emb, None).cpu().numpy()
+    assert n_est.shape == (7, B, 3)
+    assert np.all(1 - _cos(n_est, ref["n_est"].numpy()) < COS_TOL_F32)
+    normals, ex2, pr2 = net(p_d, n_d)
+    torch.cuda.synchronize()
+    assert np.array_equal(ex2.cpu().numpy(), ref["expert"].numpy())
+    assert np.all(1 - _cos(normals.cpu().numpy(), ref["normals"].numpy()) < COS_TOL_F32)
+    pr, ne, mu = get_model(net, p_d, n_d)
+    assert mu.shape == (B, 3, 3, 3, 60) and pr.shape == (7, B) and ne.shape == (7, B, 3)
+    # production dtypes
+    for dt, tol in (("bf16", 2e-3), ("f16", 5e-5)):
+        n16 = NestiNet(cfg, W, dtype=dt, device=gpu_device, max_batch=B)
+        nn_, ee_, _ = n16(p_d, n_d)
+        same = ee_.cpu().numpy() == ref["expert"].numpy()
+        assert same.mean() >= 0.75
+        assert np.all(1 - _cos(nn_.cpu().numpy()[same], ref["normals"].numpy()[same]) < tol)
+
+
 def test_other_expert_layouts_match_oracle(gpu_device):
     """The graph builder follows expert_dict / n_experts generically (models/experts_n_est.py:83-103): 4 experts
     {0:[0], 1:[1,2], 2:[2], 3:[0,1,2]} -- a 2-scale expert gets 128/2 = 64 first-block filters."""

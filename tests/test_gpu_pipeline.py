@@ -151,3 +151,27 @@ def test_cli_switching_model(dataset_dir, tmp_path, gpu_device):
         normals = np.loadtxt(os.path.join(out, nm + ".normals"))
         assert normals.shape == (len(range(0, n, 7)), 3) and np.all(np.isfinite(normals))
         assert not os.path.exists(os.path.join(out, nm + ".experts"))
+
+
+def test_end_to_end_3_gaussian_grid(gpu_device):
+    """--num_gaussians 3 model through the whole path (ball query -> 27-Gaussian MuPS -> conv_net_3g MoE): the f32
+    pipeline equals oracle patches -> oracle MuPS -> oracle network on every query of a small cloud subset."""
+    from nesti_net_amd import synth, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.pipeline import NormalEstimator
+    from oracle import mups_ref, net_ref, patches_ref
+    cfg = NestiConfig(n_gaussians=3, gmm_variance=0.111)
+    W = weights.synthetic_weights(cfg)
+    pts = synth.make_cloud("torus", n=12000, seed=21, noise=0.006)[0]
+    q = np.arange(0, 12000, 1000)
+    est = NormalEstimator(cfg, W, dtype="f32", device=gpu_device, batch=5)       # ragged batches: 5 + 5 + 2
+    normals, expert, probs = est.estimate(pts, pidx=q)
+    _, r_abs = patches_ref.patch_radii(pts, cfg.patch_radius)
+    o_pts, o_neff, _, _ = patches_ref.extract_patches(pts, q, r_abs, cfg.num_point, est.seed)
+    ref = net_ref.moe_forward(mups_ref.mups_assemble(o_pts, o_neff, 3, grid_n=3, variance=0.111), W, dtype=torch.float64,
+                              top1_only=True)
+    assert np.array_equal(expert, ref["expert"].numpy())
+    a, b = normals.astype(np.float64), ref["normals"].numpy()
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert np.all(1 - cos < 1e-5)
+    assert np.abs(probs - ref["probs"].numpy()).max() < 2e-5

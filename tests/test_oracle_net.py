@@ -43,6 +43,21 @@ def test_max_pool():
     assert y.shape == (1, 2, 2, 2, 1) and y[0, 0, 0, 0, 0] == 21 and y[0, 1, 1, 1, 0] == 63
 
 
+def test_max_pool_3_stride2_same_on_3cubed():
+    """tf.nn.max_pool3d([3,3,3], stride 2, SAME) on 3^3 (models/experts_n_est.py:238): TF's SAME rule gives
+    out = ceil(3/2) = 2 and pad_total = (2-1)*2 + 3 - 3 = 2 -> one voxel in front, so cell o covers {o, o+1}."""
+    x = torch.arange(2 * 27 * 3, dtype=torch.float64).reshape(2, 3, 3, 3, 3)
+    x = torch.sin(x)
+    y = N.max_pool3d_3s2_same(x).numpy()
+    assert y.shape == (2, 2, 2, 2, 3)
+    xn = x.numpy()
+    for z in range(2):
+        for yy in range(2):
+            for xx in range(2):
+                ref = xn[:, z:z + 2, yy:yy + 2, xx:xx + 2].max(axis=(1, 2, 3))
+                assert np.array_equal(y[:, z, yy, xx], ref)
+
+
 def test_bn_inference_eps():
     W = {"s/bn/mean": np.array([1.0]), "s/bn/var": np.array([0.0]), "s/bn/beta": np.array([0.5]),
          "s/bn/gamma": np.array([2.0])}
