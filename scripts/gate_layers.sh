@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-launch durations of the gating tower (last repetition) at batch $1 under rocprofv3 --kernel-trace
 cd /tmp && export TMPDIR=/tmp
-B=${1:-8192}
+B=${1:-8192}; [ -n "$2" ] && export $2
 rm -rf /tmp/gl && rocprofv3 --kernel-trace --output-format csv -d /tmp/gl -- python3 $GRAFT_REPO_ROOT/scripts/prof_gate.py $B 2 > /tmp/gl.log 2>&1
 f=$(find /tmp/gl -name "*kernel_trace.csv" | head -1)
 python3 - "$f" "$B" <<'PY'
