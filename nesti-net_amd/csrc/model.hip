@@ -612,8 +612,6 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.m_tiles = (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
       if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C; p.mp_mode = op.mp_mode; }
-      static const int dbg_nopool = [] { const char* e = getenv("NESTI_DEBUG_NOPOOL"); return e ? atoi(e) : 0; }();
-      if (dbg_nopool) p.pool_k = 1;   // timing experiments only: wrong results
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
       prof_begin(NESTI_PROF_CONV, rc.stream);
