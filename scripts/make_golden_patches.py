@@ -33,6 +33,11 @@ CASES = [
          queries=list(range(16)) + list(range(777, 100000, 6250))),
     dict(name="box20k_smallP", cloud=dict(shape="box", n=20000, seed=1236), radii=[0.02, 0.06], P=64,
          queries=list(range(8)) + list(range(31, 20000, 2500))),
+    # PCPNet's varying-density sets and strongest noise level (BASELINE configs 3 / 4)
+    dict(name="torus40k_gradient", cloud=dict(shape="torus", n=40000, seed=1237, noise=0.00125, density="gradient"),
+         radii=[0.01, 0.03, 0.05], P=512, queries=list(range(6)) + list(range(123, 40000, 4000))),
+    dict(name="sphere40k_striped_noise012", cloud=dict(shape="sphere", n=40000, seed=1238, noise=0.012, density="striped"),
+         radii=[0.01, 0.03, 0.05], P=512, queries=list(range(6)) + list(range(77, 40000, 4000))),
 ]
 
 
@@ -67,7 +72,7 @@ def run_case(case, outdir):
     path = os.path.join(outdir, "patches_%s.npz" % case["name"])
     np.savez_compressed(
         path, cloud_shape=case["cloud"]["shape"], cloud_n=case["cloud"]["n"], cloud_seed=case["cloud"]["seed"],
-        cloud_noise=case["cloud"].get("noise", 0.0), radii=np.asarray(case["radii"]), P=P, seed=SEED,
+        cloud_noise=case["cloud"].get("noise", 0.0), cloud_density=case["cloud"].get("density") or "", radii=np.asarray(case["radii"]), P=P, seed=SEED,
         queries=np.asarray(case["queries"], np.int32), r_abs=r_abs, points=points, n_eff=n_eff,
         ball_concat=np.concatenate(sets).astype(np.int32), ball_offsets=np.asarray(offs, np.int64))
     print(path, "M=%d" % M, "n_eff mean", n_eff.mean(0), "ball mean",
@@ -77,5 +82,7 @@ def run_case(case, outdir):
 if __name__ == "__main__":
     out = os.path.join(REPO, "tests", "golden")
     os.makedirs(out, exist_ok=True)
+    only = set(sys.argv[1:])          # optional: names of the cases to (re)generate
     for c in CASES:
-        run_case(c, out)
+        if not only or c["name"] in only:
+            run_case(c, out)

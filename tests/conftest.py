@@ -26,7 +26,8 @@ def load_golden_patches(path):
     from nesti_net_amd import synth
     g = dict(np.load(path))
     pts, nrm = synth.make_cloud(shape=str(g["cloud_shape"]), n=int(g["cloud_n"]), seed=int(g["cloud_seed"]),
-                                noise=float(g["cloud_noise"]))
+                                noise=float(g["cloud_noise"]),
+                                density=(str(g["cloud_density"]) or None) if "cloud_density" in g else None)
     g["pts"], g["normals"] = pts, nrm
     g["P"], g["seed"] = int(g["P"]), int(g["seed"])
     M, S = g["n_eff"].shape
