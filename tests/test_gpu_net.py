@@ -363,3 +363,17 @@ def test_empty_batch_is_a_no_op(setup, net_f32, gpu_device):
     normals, expert, probs = net_f32(p, n)
     assert normals.shape == (0, 3) and expert.shape == (0,) and probs.shape == (0, 7)
     assert net_f32.mups(p, n).shape[0] == 0
+
+
+def test_barrier_free_tap_kernel_variant_matches_oracle(gpu_device):
+    """conv_taps.hip (opt-in, NESTI_CONV_TAPS=1: per-wave weight fragments from L2, one barrier per channel chunk) is a
+    second implementation of the k^3-tap layers; the switch is read once per process, so the f32 / bf16 oracle
+    comparisons of this file are re-run in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NESTI_CONV_TAPS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
+                        "f32_forward_top1 or 16bit_modes or switching_model or 3_gaussian"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
