@@ -70,6 +70,56 @@ __global__ __launch_bounds__(512) void k(const uint4* in, float* out, int iters,
   if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
 }
 
+// The same wave tile (64 rows x 128 columns) built from v_mfma_f32_16x16x32_bf16: 4 x 8 tiles of 16x16, one iteration = 32 k =
+// 32 MFMAs, 4 A + 8 B fragment reads -- the instruction a 16-row padding-skip granularity would need.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+template <int MODE>
+__global__ __launch_bounds__(512) void k16(const uint4* in, float* out, int iters, long long* cyc) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint4* l = reinterpret_cast<uint4*>(smem);
+  for (int i = tid; i < 8192; i += blockDim.x) l[i] = in[i & 1023];
+  __syncthreads();
+  f32x4 acc[4][8];
+  for (int mi = 0; mi < 4; ++mi) for (int ni = 0; ni < 8; ++ni) for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+  uint4 a[4], b[8];
+  for (int i = 0; i < 4; ++i) a[i] = in[lane + i * 64];
+  for (int i = 0; i < 8; ++i) b[i] = in[lane + (4 + i) * 64];
+  long long t0 = __builtin_readcyclecounter();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  for (int it = 0; it < iters; ++it) {
+    if (MODE >= 3 && (it & 3) == 0) {   // 32 KB weight-tile DMA per 4 iterations (= 8 K-steps of 16)
+      const unsigned char* src = reinterpret_cast<const unsigned char*>(in) + (((it >> 2) & 3) * 32768);
+      for (int q = 0; q < 4; ++q) {
+        const int piece = wave * 4 + q;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src + piece * 1024 + lane * 16), "s"(lds0 + 65536 + piece * 1024) : "memory");
+      }
+    }
+    if (MODE >= 1) {
+      const int base = ((it * 12) & 127) * 64 + lane;
+      for (int i = 0; i < 4; ++i) a[i] = l[base + i * 64];
+      for (int i = 0; i < 8; ++i) b[i] = l[base + (4 + i) * 64];
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 8; ++ni)
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[mi]), __builtin_bit_cast(bf16x8, b[ni]), acc[mi][ni], 0, 0, 0);
+    if ((MODE == 2 || MODE == 3) && (it & 3) == 3) {
+      if (MODE >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+  long long t1 = __builtin_readcyclecounter();
+  float s = 0;
+  for (int mi = 0; mi < 4; ++mi) for (int ni = 0; ni < 8; ++ni) for (int r = 0; r < 4; ++r) s += acc[mi][ni][r];
+  out[blockIdx.x * blockDim.x + tid] = s;
+  if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 int main() {
   uint4* in; float* out; long long* cyc;
   hipMalloc(&in, 1 << 20); hipMemset(in, 0x3c, 1 << 20);
@@ -97,6 +147,24 @@ int main() {
         if (rep) printf("mode %d (%s) waves/SIMD %.0f: %.1f s_memtime ticks per MFMA per wave, %.1f TFLOP/s chip (%.3f ms)\n", mode,
                names[mode], waves_per_simd, c / mf,
                256.0 * (threads / 64) * mf * 32768 / (ms * 1e-3) / 1e12, ms);
+      }
+    }
+  for (int mode = 0; mode < 4; ++mode)
+    for (int threads : {256, 512}) {
+      if (mode >= 3 && threads != 512) continue;
+      for (int rep = 0; rep < 2; ++rep) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0);
+        const int it16 = iters / 2;
+        if (mode == 0) hipLaunchKernelGGL(k16<0>, dim3(256), dim3(threads), 131072, 0, in, out, it16, cyc);
+        else if (mode == 1) hipLaunchKernelGGL(k16<1>, dim3(256), dim3(threads), 131072, 0, in, out, it16, cyc);
+        else if (mode == 2) hipLaunchKernelGGL(k16<2>, dim3(256), dim3(threads), 131072, 0, in, out, it16, cyc);
+        else hipLaunchKernelGGL(k16<3>, dim3(256), dim3(threads), 131072, 0, in, out, it16, cyc);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double mf = (double)it16 * 32;                      // 16x16x32 MFMAs per wave (16384 FLOP each)
+        if (rep) printf("16x16x32 mode %d (%s) waves/SIMD %.0f: %.1f TFLOP/s chip (%.3f ms)\n", mode, names[mode], threads / 256.0,
+               256.0 * (threads / 64) * mf * 16384 / (ms * 1e-3) / 1e12, ms);
       }
     }
   return 0;
