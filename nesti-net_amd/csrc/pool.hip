@@ -173,6 +173,13 @@ __global__ void scatter3_kernel(const float* __restrict__ src, int sstride, cons
   for (int c = 0; c < 3; ++c) out[d * 3 + c] = src[(size_t)j * sstride + c];
 }
 
+// Zeroes the routing counters.  A kernel, not hipMemsetAsync: inside a captured hipGraph the memset node of this
+// 4*E-byte region did not take effect on replay (ROCm 7.2, gfx950) -- the counters then accumulated from replay to
+// replay and the expert towers read stale list entries.
+__global__ void zero_counts_kernel(int32_t* __restrict__ counts, int n) {
+  if ((int)threadIdx.x < n) counts[threadIdx.x] = 0;
+}
+
 int grid_for(long long work) {
   long long g = (work + kThreads - 1) / kThreads;
   if (g > 256 * 16) g = 256 * 16;
@@ -213,7 +220,7 @@ int launch_gate_finish(const float* logits, int lstride, int B, int E, float* pr
                        int32_t* counts, int32_t* lists, hipStream_t stream) {
   if (B <= 0) return 0;
   if (E > NESTI_MAX_EXPERTS) NESTI_FAIL("gate_finish: too many experts");
-  if (counts) NESTI_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * E, stream));
+  if (counts) hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, stream, counts, E);
   hipLaunchKernelGGL(gate_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, E,
                      probs, expert, counts, lists);
   NESTI_CHECK_HIP(hipGetLastError());
@@ -223,7 +230,7 @@ int launch_gate_finish(const float* logits, int lstride, int B, int E, float* pr
 int launch_switch_finish(const float* logits, int lstride, int B, float threshold, float* probs, int32_t* expert,
                          int32_t* counts, int32_t* lists, hipStream_t stream) {
   if (B <= 0) return 0;
-  if (counts) NESTI_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * 2, stream));
+  if (counts) hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, stream, counts, 2);
   hipLaunchKernelGGL(switch_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, threshold,
                      probs, expert, counts, lists);
   NESTI_CHECK_HIP(hipGetLastError());
@@ -232,7 +239,7 @@ int launch_switch_finish(const float* logits, int lstride, int B, float threshol
 
 int launch_route(const int32_t* expert, int B, int E, int32_t* counts, int32_t* lists, hipStream_t stream) {
   if (B <= 0) return 0;
-  NESTI_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * E, stream));
+  hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, stream, counts, E);
   hipLaunchKernelGGL(route_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, expert, B, E, counts, lists);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;

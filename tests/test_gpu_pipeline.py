@@ -89,24 +89,37 @@ def test_cli_writes_reference_file_contract(dataset_dir, tmp_path, gpu_device):
 
 def test_hipgraph_replay_matches_eager(gpu_device):
     """BASELINE config 4 ingredient: the captured forward (hipGraph) replays bit-identically, in f16, over a
-    stream of clouds of different density without host synchronisation in between."""
+    stream of clouds of different density without host synchronisation in between.  The gate is calibrated so that
+    the queries spread over all experts: with everything routed to one expert the device-side routing counters
+    saturate at the batch size and a replay that fails to reset them goes unnoticed (it did: the hipMemsetAsync node
+    that used to clear them was not effective on replay).  Full batches (replays) and ragged tails (eager launches on
+    the same workspace) alternate, and every cloud is run twice."""
     from nesti_net_amd import synth, weights
+    from nesti_net_amd.calibrate import calibrate_gate
     from nesti_net_amd.config import NestiConfig
     from nesti_net_amd.pipeline import NormalEstimator
+    from nesti_net_amd.provider import CloudPatches
     cfg = NestiConfig()
     W = weights.synthetic_weights(cfg)
-    eager = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=256)
-    graphed = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=256, use_graph=True)
     clouds = [synth.make_cloud("sphere", n=6000, seed=5, density="gradient")[0],
               synth.make_cloud("box", n=5000, seed=6, density="striped")[0],
               synth.make_cloud("torus", n=4000, seed=7, noise=0.006)[0]]
+    cp = CloudPatches(clouds[2], cfg, device=gpu_device)
+    sp, sn = cp.build(0, 512)
+    W = calibrate_gate(cfg, W, sp, sn, device=gpu_device)
+    eager = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=256)
+    graphed = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=256, use_graph=True)
     prepared = [graphed.prepare(c, pidx=np.arange(0, len(c), 9)) for c in clouds]
-    outs = [graphed.run(pc) for pc in prepared]          # enqueued back to back, no sync
+    outs = [graphed.run(pc) for pc in prepared + prepared]          # enqueued back to back, no sync
     torch.cuda.synchronize()
-    for c, (n_g, e_g, p_g) in zip(clouds, outs):
+    seen = set()
+    for k, (n_g, e_g, p_g) in enumerate(outs):
+        c = clouds[k % 3]
         n_e, e_e, p_e = eager.estimate(c, pidx=np.arange(0, len(c), 9))
-        assert np.array_equal(n_g.cpu().numpy(), n_e) and np.array_equal(e_g.cpu().numpy(), e_e)
-        assert np.array_equal(p_g.cpu().numpy(), p_e)
+        assert np.array_equal(e_g.cpu().numpy(), e_e), "routing differs on run %d" % k
+        assert np.array_equal(n_g.cpu().numpy(), n_e) and np.array_equal(p_g.cpu().numpy(), p_e)
+        seen |= set(e_e.tolist())
+    assert len(seen) >= 5, "the calibrated gate should exercise most experts: %s" % sorted(seen)
 
 
 def test_two_stream_batches_match_single_stream(gpu_device):
