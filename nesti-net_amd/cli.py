@@ -11,7 +11,6 @@ import argparse
 import os
 import sys
 
-import numpy as np
 import torch
 
 from . import textio

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .config import ARCH_EXPERTS, ARCH_MULTI, ARCH_SINGLE, DTYPES, NestiConfig
+from .config import ARCH_MULTI, ARCH_SINGLE, DTYPES, NestiConfig
 
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
 
