@@ -22,7 +22,8 @@ n = len(ka) // 2
 for k, k2 in list(zip(ka, kb))[n:n + 18]:
     c, d = a[k], b[k2]
     wc = c["SQ_WAVE_CYCLES"]
-    print("%-34s wgs %5d mfma %.3g valu %.3g salu %.3g lds %.3g | wait %.2f stall %.2f active %.2f | ldsconf %.3f ldswait %.2f vmem %.3g gui %.3g" % (
-        k[1], k[2], c["SQ_INSTS_MFMA"], c["SQ_INSTS_VALU"], c["SQ_INSTS_SALU"], c["SQ_INSTS_LDS"], c["SQ_WAIT_ANY"] / wc, c["SQ_WAIT_INST_ANY"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc,
-        d["SQ_LDS_BANK_CONFLICT"] / max(1, d["SQ_LDS_IDX_ACTIVE"]), d["SQ_WAIT_INST_LDS"] / wc, d["SQ_INSTS_VMEM_RD"], d["GRBM_GUI_ACTIVE"]))
+    busy = c["SQ_INSTS_MFMA"] * 32.0 / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)     # 32 cycles per 32x32x16 MFMA, 1024 SIMDs, GUI_ACTIVE summed over 8 XCDs
+    print("%-34s wgs %5d | mfma %.3g (pipe busy %4.1f %%) valu %.3g salu %.3g lds %.3g | wave time: wait %.2f issue-stall %.2f active %.2f | lds conflict %.3f" % (
+        k[1], k[2], c["SQ_INSTS_MFMA"], 100 * busy, c["SQ_INSTS_VALU"], c["SQ_INSTS_SALU"], c["SQ_INSTS_LDS"], c["SQ_WAIT_ANY"] / wc, c["SQ_WAIT_INST_ANY"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc,
+        d["SQ_LDS_BANK_CONFLICT"] / max(1, d["SQ_LDS_IDX_ACTIVE"])))
 PY
