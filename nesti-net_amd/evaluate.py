@@ -40,3 +40,43 @@ def evaluate_set(normal_results_path, data_path, dataset_list_file, sparse_patch
         per_shape[shape] = shape_metrics(pred, gt)
     avg = {k: float(np.mean([m[k] for m in per_shape.values()])) for k in ("rms", "rms_o", "pgp5", "pgp10")}
     return per_shape, avg
+
+
+def main(argv=None):
+    """Command-line twin of the reference's ``utils/evaluate.py`` (``:22-29`` flags, ``:57-60`` summary directory,
+    ``:192-198`` log lines): for each list in ``--dataset_list`` writes
+    ``<normal_results_path>/summary/<dataset>_evaluation_results.txt`` and prints the same lines."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--normal_results_path", default="log/experts/pcpnet_results/", help="Log dir [default: log]")
+    ap.add_argument("--data_path", type=str, default="data/pcpnet/", help="Relative path to data directory")
+    ap.add_argument("--sparse_patches", type=int, default=True,
+                    help="Evaluate on a sparse subset or on the entire point cloud")
+    ap.add_argument("--dataset_list", type=str, default=["testset_temp"], nargs="+",
+                    help="list of .txt files containing sets of point cloud names for evaluation")
+    flags = ap.parse_args(argv)
+    outdir = os.path.join(flags.normal_results_path, "summary/")
+    os.makedirs(outdir, exist_ok=True)
+    results = {}
+    for dataset in flags.dataset_list:
+        listfile = dataset if dataset.endswith(".txt") else dataset + ".txt"
+        name = listfile[:-4]
+        per_shape, avg = evaluate_set(flags.normal_results_path, flags.data_path, listfile, bool(flags.sparse_patches))
+        shapes = list(per_shape)
+        with open(os.path.join(outdir, name + "_evaluation_results.txt"), "w") as log:
+            def log_string(out_str):
+                log.write(out_str + "\n")
+                print(out_str)
+            log_string("RMS per shape: " + str([per_shape[s]["rms"] for s in shapes]))
+            log_string("RMS not oriented (shape average): " + str(avg["rms"]))
+            log_string("RMS oriented (shape average): " + str(avg["rms_o"]))
+            log_string("PGP10 per shape: " + str([per_shape[s]["pgp10"] for s in shapes]))
+            log_string("PGP5 per shape: " + str([per_shape[s]["pgp5"] for s in shapes]))
+            log_string("PGP10 average: " + str(avg["pgp10"]))
+            log_string("PGP5 average: " + str(avg["pgp5"]))
+        results[name] = avg
+    return results
+
+
+if __name__ == "__main__":
+    main()
