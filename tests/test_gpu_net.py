@@ -356,6 +356,42 @@ def test_other_expert_layouts_match_oracle(gpu_device):
     assert np.array_equal(expert.cpu().numpy(), ref["expert"].numpy())
 
 
+def test_limits_four_scales_eight_experts(gpu_device):
+    """The ABI's limits (NESTI_MAX_SCALES = 4, NESTI_MAX_EXPERTS = 8): MuPS with 80 channels (channel stride 128, two
+    K-chunks in the first layers), the default expert assignment of models/experts_n_est.py:83-96 (8 // 4 = 2 experts
+    per scale, no multi-scale expert), patches straight from the HIP ball query with P = 128."""
+    from nesti_net_amd import synth, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from nesti_net_amd.provider import CloudPatches
+    from oracle import mups_ref, net_ref, patches_ref
+    cfg = NestiConfig(patch_radius=[0.01, 0.02, 0.04, 0.06], num_point=128, n_experts=8, expert_dict=None)
+    cfg.expert_dict = cfg.default_expert_dict()
+    assert cfg.expert_dict == {0: [0], 1: [0], 2: [1], 3: [1], 4: [2], 5: [2], 6: [3], 7: [3]}
+    W = weights.synthetic_weights(cfg)
+    assert W["inception1gating_conv_conv1/weights"].shape == (1, 1, 1, 80, 128) and W["fc4noise/weights"].shape == (128, 8)
+    pts = synth.make_cloud("torus", n=30000, seed=9, noise=0.00125)[0]
+    q = np.arange(0, 30000, 5000)
+    cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
+    p_d, n_d = cp.build(0, len(q))
+    o_pts, o_neff, _, _ = patches_ref.extract_patches(pts, q, cp.r_abs, cfg.num_point, cp.seed)
+    assert np.array_equal(p_d.cpu().numpy().view(np.uint32), o_pts.view(np.uint32)) and np.array_equal(n_d.cpu().numpy(), o_neff)
+    net = NestiNet(cfg, W, dtype="f32", device=gpu_device, max_batch=len(q))
+    assert net.mups_cstride == 128
+    mups = net.mups(p_d, n_d)
+    mups_o = mups_ref.mups_assemble(o_pts, o_neff, 4)
+    assert np.abs(mups.cpu().numpy()[..., :80] - mups_o).max() < 2e-5 and not mups.cpu().numpy()[..., 80:].any()
+    ref = net_ref.moe_forward(mups_o, W, expert_dict=cfg.expert_dict, dtype=torch.float64)
+    probs, expert = net.gate(mups)
+    assert np.abs(probs.cpu().numpy() - ref["probs"].numpy()).max() < PROB_TOL_F32
+    assert np.array_equal(expert.cpu().numpy(), ref["expert"].numpy())
+    n_est = net.experts(mups, None).cpu().numpy()
+    assert n_est.shape == (8, len(q), 3)
+    assert np.all(1 - _cos(n_est, ref["n_est"].numpy()) < COS_TOL_F32)
+    normals, _, _ = net(p_d, n_d)
+    assert np.all(1 - _cos(normals.cpu().numpy(), ref["normals"].numpy()) < COS_TOL_F32)
+
+
 def test_empty_batch_is_a_no_op(setup, net_f32, gpu_device):
     cfg, W, pts, n_eff = setup
     p = torch.zeros((0, 1536, 3), dtype=torch.float32, device=gpu_device)
