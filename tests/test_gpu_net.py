@@ -413,3 +413,37 @@ def test_barrier_free_tap_kernel_variant_matches_oracle(gpu_device):
                         "f32_forward_top1 or 16bit_modes or switching_model or 3_gaussian"], env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_error_behaviour_at_the_boundary(setup, net_f32, gpu_device):
+    """The C-ABI reports misuse through its status code + nesti_last_error (raised as NestiError by the host mirror)
+    instead of faulting: workspace too small, missing or mis-shaped variables, wrong model kind, null pointers."""
+    import ctypes
+    from nesti_net_amd import _lib, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    cfg, W, pts, n_eff = setup
+    lib = _lib.load()
+    p = torch.as_tensor(pts[:4], device=gpu_device)
+    n = torch.as_tensor(n_eff[:4], device=gpu_device).to(torch.int32)
+    small = torch.empty(1 << 20, dtype=torch.uint8, device=gpu_device)
+    with pytest.raises(_lib.NestiError, match="workspace too small"):
+        net_f32.forward(p, n, ws=small)
+    # the call after a failed one works and the workspace was not touched beyond its end
+    normals, expert, probs = net_f32(p, n)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(normals).all())
+    bad = dict(W)
+    del bad["inception2gating_conv_conv3/weights"]
+    with pytest.raises(_lib.NestiError, match="inception2gating_conv_conv3/weights"):
+        NestiNet(cfg, bad, dtype="bf16", device=gpu_device, max_batch=4)
+    bad = dict(W)
+    bad["fc4noise/biases"] = np.zeros(6, np.float32)
+    with pytest.raises(_lib.NestiError, match="fc4noise/biases"):
+        NestiNet(cfg, bad, dtype="bf16", device=gpu_device, max_batch=4)
+    ss = NestiNet(NestiConfig.for_model("ss_norm_est"), weights.synthetic_weights(NestiConfig.for_model("ss_norm_est")),
+                  dtype="bf16", device=gpu_device, max_batch=4)
+    with pytest.raises(_lib.NestiError, match="no gating net"):
+        ss.gate(torch.zeros((4, 8, 8, 8, 64), dtype=torch.bfloat16, device=gpu_device))
+    assert lib.nesti_forward(net_f32._handle, None, None, 4, None, 0, None, None, None, None) != 0
+    assert b"null argument" in lib.nesti_last_error()
