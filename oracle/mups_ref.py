@@ -4,11 +4,18 @@ reference's MuPS / 3DmFV arithmetic.
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this module.  The product path (``nesti-net_amd/``) never does.
 
-Parity status: **unpinned at the TensorFlow boundary** -- TensorFlow 1.12 is not
-installable here, so ``utils/tf_util.py`` cannot be executed.  ``mups_literal``
-is a line-by-line numpy transcription of ``utils/tf_util.py:655-753``;
-``mups_separable`` is an independent derivation (SURVEY.md §8(a')) and the two are
-checked against each other in ``tests/test_oracle_mups.py``.
+Parity status: **partly pinned**.  TensorFlow 1.12 is not installable here, so
+``utils/tf_util.py:655-753`` (get_3dmfv_n_est) itself cannot be executed.  ``mups_literal`` is a
+line-by-line numpy transcription of it.  The reference also ships a numpy twin of the same
+construction, ``utils/utils.py:260-330`` (get_3DmFV): identical Gaussian density, derivative
+terms, scale constants, max/min/sum reductions, power + L2 normalisation and channel order; it
+differs from the TF function in exactly four places (no ``w p / sum(w p)`` posterior, no padding
+mask, division by the row count instead of ``n_eff``, L2 norm without epsilon).  With those four
+switched through keyword flags, ``mups_literal`` reproduces the outputs of the reference's numpy
+function run in this container (``scripts/make_golden_3dmfv.py`` -> ``tests/golden/fv_numpy_ref.npz``)
+to 1e-13, and ``grid_gmm`` equals its ``get_3d_grid_gmm`` exactly (``tests/test_oracle_mups.py``).
+The four TF-only lines (``:693-702``, ``:722-729``, ``:738-740``) remain transcription-only.
+``mups_separable`` is an independent derivation (SURVEY.md §8(a')) cross-checked against the literal form.
 
 All file:line citations are relative to the reference tree.
 """
@@ -30,10 +37,16 @@ def grid_gmm(n=8, variance=0.0156):
     return w, means, np.sqrt(cov)
 
 
-def mups_literal(points, w, mu, sigma, n_eff, dtype=np.float64):
+def mups_literal(points, w, mu, sigma, n_eff, dtype=np.float64, posterior=True, masked=True, per_n_eff=True,
+                 l2_eps=1e-12, flatten=True):
     """One scale.  Transcribes ``utils/tf_util.py:655-753`` (flatten=True).
 
-    points [B,P,3], n_eff [B] -> fv [B, 20*G]."""
+    points [B,P,3], n_eff [B] -> fv [B, 20*G].
+
+    The keyword flags exist only to pin this transcription against the reference's numpy twin
+    ``utils/utils.py:260-330``: ``posterior=False`` (Q = p, ``:300-301`` there), ``masked=False`` (no padding
+    mask), ``per_n_eff=False`` (divide by the row count, ``:313-315``), ``l2_eps=0`` (``l2_normalize``,
+    ``:247-255``) and ``flatten=False`` ([B,20,G], ``:331-332``) make it that function."""
     points = np.asarray(points, dtype)
     w = np.asarray(w, dtype)
     mu = np.asarray(mu, dtype)
@@ -52,10 +65,10 @@ def mups_literal(points, w, mu, sigma, n_eff, dtype=np.float64):
         np.exp(dtype(-0.5) * np.sum(np.square(z), axis=3))             # :686-687
     r = np.arange(P)[None, :, None]                                    # :690-692
     mask = r > n_orig[:, None, None]                                   # :693-695  (NOT >=)
-    mask = np.broadcast_to(mask, (B, P, G))
+    mask = np.broadcast_to(mask, (B, P, G)) if masked else np.zeros((B, P, G), bool)
     w_zero_comp = np.where(mask, batch_w, dtype(0))                    # :697
     w_p = p_per_point * batch_w                                        # :699
-    Q = w_p / np.sum(w_p, axis=-1, keepdims=True)                      # :700
+    Q = w_p / np.sum(w_p, axis=-1, keepdims=True) if posterior else p_per_point   # :700
     Q = np.where(mask, dtype(0), Q)                                    # :702
     Qd = Q[..., None]                                                  # :703
     d_pi_all = ((Q - batch_w + w_zero_comp) / np.sqrt(batch_w))[..., None]   # :709
@@ -67,7 +80,7 @@ def mups_literal(points, w, mu, sigma, n_eff, dtype=np.float64):
     d_sigma = (1 / np.sqrt(2 * w_per_batch_per_d)) * np.concatenate(
         [d_sig_all.max(1), d_sig_all.min(1), d_sig_all.sum(1)], axis=2)  # :718-719
     with np.errstate(divide="ignore", invalid="ignore"):
-        eff = n_orig.astype(np.float32).astype(dtype)[:, None, None]   # :722
+        eff = n_orig.astype(np.float32).astype(dtype)[:, None, None] if per_n_eff else dtype(P)   # :722
         d_pi, d_mu, d_sigma = d_pi / eff, d_mu / eff, d_sigma / eff    # :727-729
     alpha = dtype(0.5)                                                 # :732-735
     d_pi = np.sign(d_pi) * np.power(np.abs(d_pi), alpha)
@@ -75,8 +88,10 @@ def mups_literal(points, w, mu, sigma, n_eff, dtype=np.float64):
     d_sigma = np.sign(d_sigma) * np.power(np.abs(d_sigma), alpha)
 
     def l2n(x):  # tf.nn.l2_normalize(axis=1): x * rsqrt(max(sum(x^2), 1e-12))   :738-740
-        return x / np.sqrt(np.maximum(np.sum(np.square(x), axis=1, keepdims=True), dtype(1e-12)))
+        return x / np.sqrt(np.maximum(np.sum(np.square(x), axis=1, keepdims=True), dtype(l2_eps)))
     d_pi, d_mu, d_sigma = l2n(d_pi), l2n(d_mu), l2n(d_sigma)
+    if not flatten:
+        return np.transpose(np.concatenate([d_pi, d_mu, d_sigma], axis=2), (0, 2, 1))   # :749-750
     flat = lambda x: np.transpose(x, (0, 2, 1)).reshape(B, -1)         # :744-746
     return np.concatenate([flat(d_pi), flat(d_mu), flat(d_sigma)], axis=1)  # :747
 

@@ -87,3 +87,34 @@ def test_fp32_close_to_fp64():
     a = M.mups_literal(pts, w, mu, sg, n_eff)
     b = M.mups_literal(pts.astype(np.float32), w, mu, sg, n_eff, dtype=np.float32)
     assert np.abs(a - b).max() < 5e-6
+
+
+def test_oracle_pinned_to_reference_numpy_3dmfv():
+    """The reference's own numpy twin of the TF 3DmFV (utils/utils.py:260-332, run in the build container by
+    scripts/make_golden_3dmfv.py) pins the oracle's transcription: Gaussian density, derivative terms, 1/sqrt(w) and
+    1/sqrt(2w) scales, max/min/sum reductions, power + L2 normalisation, channel order and [20, G] layout.  The four
+    places where get_3dmfv_n_est differs (posterior, padding mask, n_eff divisor, L2 epsilon) are switched off through
+    mups_literal's flags.  get_3d_grid_gmm (utils/utils.py:70-95) pins grid_gmm for both grid sizes."""
+    import os
+    from conftest import GOLDEN, golden_patch_files, load_golden_patches
+    from oracle import mups_ref
+    ref = np.load(os.path.join(GOLDEN, "fv_numpy_ref.npz"))
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid20k" in p][0])
+    P = int(g["P"])
+    for n, var in ((8, 0.0156), (3, 0.111)):
+        w, mu, sig = mups_ref.grid_gmm(n, var)
+        assert np.array_equal(w, ref["gmm%d_weights" % n]) and np.array_equal(mu, ref["gmm%d_means" % n])
+        assert np.array_equal(sig, np.sqrt(ref["gmm%d_covariances" % n]))
+        rows = ref["fv%d_rows" % n]
+        pts = np.stack([g["points"][q, s * P:(s + 1) * P] for q, s in rows]).astype(np.float64)
+        kw = dict(posterior=False, masked=False, per_n_eff=False, l2_eps=0.0, flatten=False)
+        fv = mups_ref.mups_literal(pts, w, mu, sig, np.full(len(rows), P), **kw)
+        want = ref["fv%d" % n]
+        assert fv.shape == want.shape == (len(rows), 20, n ** 3)
+        assert np.abs(fv - want).max() < 1e-13 * max(1.0, np.abs(want).max())
+        # before power / L2 normalisation: undo them on the oracle side is not possible, so compare the raw statistics
+        # through the separately saved normalize=False output, channel by channel up to the per-channel L2 factor
+        raw = ref["fv%d_raw" % n]
+        sp = np.sign(raw) * np.sqrt(np.abs(raw))
+        sp = sp / np.linalg.norm(sp, axis=2, keepdims=True)
+        assert np.abs(sp - want[:2]).max() < 1e-12
