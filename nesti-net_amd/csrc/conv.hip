@@ -49,17 +49,18 @@ constexpr int kPoolStride = 272;              // bytes per row of the fp32 [512]
 //   shaped to be skippable and dealt to the SIMDs as a Latin square (SIMD c gets one tile of every z slab and one
 //   of every y slab): every tap then leaves all four pipes (nearly) the same number of live tiles.
 //   8^3: tile = x 0..7 x y pair yp x z pair s, s = 2*(wave>>2) + mi, yp = (c - s) & 3, c = wave & 3;
-//   4^3: tile = x 0..3 x y pair yp x plane z = s of the 4 points of group pg, 2*yp + pg = (c - s) & 3.
+//   4^3: tile = the x-line (y, z) of all 8 points of the workgroup, z = s, y = (c - s) & 3 -- both y and z skip at
+//        single-voxel granularity (issued/nominal 0.5625 for the 4^3 taps; 0.66 with (4x,2y) half-planes of 4 points).
 __device__ __forceinline__ int tile_row(int remap, int log2S, int wave, int mi, int l) {
   if (!remap) return wave * 64 + mi * 32 + l;
   const int c = wave & 3, s = 2 * (wave >> 2) + mi;
   const int q = (c - s) & 3;
   if (log2S == 3) return ((2 * s + (l >> 4)) << 6) + ((2 * q + ((l >> 3) & 1)) << 3) + (l & 7);
-  return (((q & 1) * 4 + (l >> 3)) << 6) + (s << 4) + ((2 * (q >> 1) + ((l >> 2) & 1)) << 2) + (l & 3);
+  return ((l >> 2) << 6) + (s << 4) + (q << 2) + (l & 3);
 }
 // 16-B slot swizzle key of an LDS input row: the rows one ds_read_b128 lane group touches must differ in
 // (row & 1, key).  Natural and 8^3 tiles: four runs of 4 consecutive rows that differ in row bits 2..3; remapped 4^3
-// tiles: runs of 4 rows from 4 different points (row bits 6..7).
+// tiles: runs of 4 rows from different points -- the points of one lane group differ in their low two bits (row bits 6..7).
 // Branch-free: key = ((row >> 1) & m_lo) | (((row >> 6) & m_hi) << 1) with (m_lo, m_hi) = (7, 0) or (1, 3).
 struct SwzKey {
   int m_lo, m_hi;

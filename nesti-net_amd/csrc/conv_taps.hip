@@ -14,7 +14,7 @@
 //     in LDS is swapped.
 //   * waves c and c+4 share a SIMD and are the two row halves of column group c: every matrix pipe sees all 16
 //     row tiles, so skipping the tiles that a padding tap pushes entirely outside the volume shortens every pipe's
-//     work equally.  Tiles are shaped for that: (8x,2y,2z) blocks at 8^3 when k >= 4, (4x,2y) half-planes of 4
+//     work equally.  Tiles are shaped for that: (8x,2y,2z) blocks at 8^3 when k >= 4, x-lines of all 8
 //     points at 4^3, plain row runs otherwise (p.remap, kernels.h).
 //   * the epilogue always goes through the fp32 LDS tile (bias + ReLU, then full-resolution store and/or the fused
 //     2^3 max-pool).
@@ -71,10 +71,10 @@ __global__ __launch_bounds__(kThreads) void conv_taps_kernel(const ConvParams p)
   if (remap && log2S == 3) {            // (8x, 2y, 2z) blocks, t = 4 zp + yp
     zl = l32 >> 4; yl = (l32 >> 3) & 1; xl = l32 & 7;
     off_l = zl * 64 + yl * 8 + xl;
-  } else if (remap) {                   // 4^3: (4x, 2y) half-plane of 4 points, t = 8 pg + 2 z + yp
-    zl = 0; yl = (l32 >> 2) & 1; xl = l32 & 3;
-    off_l = (l32 >> 3) * 64 + yl * 4 + xl;
-    key_mask = 1; key_hi = (l32 >> 3) << 1;     // swizzle key = ((row >> 1) & 1) | (point << 1)
+  } else if (remap) {                   // 4^3: the x-line (y, z) of all 8 points, t = 4 z + y
+    zl = 0; yl = 0; xl = l32 & 3;
+    off_l = (l32 >> 2) * 64 + xl;
+    key_mask = 1; key_hi = ((l32 >> 2) & 3) << 1;     // swizzle key = ((row >> 1) & 1) | ((point & 3) << 1)
   } else {                              // rows [32t, 32t+32)
     const int lv = l32 & (V - 1), Sm = (1 << log2S) - 1;
     zl = lv >> (2 * log2S); yl = (lv >> log2S) & Sm; xl = lv & Sm;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void conv_taps_kernel(const ConvParams p)
   for (int i = 0; i < 8; ++i) {
     const int t = 8 * mh + i;
     if (remap && log2S == 3) { base_t[i] = 128 * (t >> 2) + 16 * (t & 3); zt[i] = 2 * (t >> 2); yt[i] = 2 * (t & 3); }
-    else if (remap) { base_t[i] = 256 * (t >> 3) + 16 * ((t >> 1) & 3) + 8 * (t & 1); zt[i] = (t >> 1) & 3; yt[i] = 2 * (t & 1); }
+    else if (remap) { base_t[i] = 16 * (t >> 2) + 4 * (t & 3); zt[i] = t >> 2; yt[i] = t & 3; }
     else { const int tv = (32 * t) & (V - 1); base_t[i] = 32 * t; zt[i] = tv >> (2 * log2S); yt[i] = (tv >> log2S) & ((1 << log2S) - 1); }
   }
 
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(kThreads) void conv_taps_kernel(const ConvParams p)
           const int l = (r & 3) + 8 * (r >> 2) + 4 * khalf;
           int row;
           if (remap && log2S == 3) row = base_t[i] + (l >> 4) * 64 + ((l >> 3) & 1) * 8 + (l & 7);
-          else if (remap) row = base_t[i] + (l >> 3) * 64 + ((l >> 2) & 1) * 4 + (l & 3);
+          else if (remap) row = base_t[i] + (l >> 2) * 64 + (l & 3);
           else row = base_t[i] + l;
           *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = fmaxf(acc[i][r] + bv, act_floor);
         }

@@ -41,8 +41,8 @@ struct ConvParams {
   void* mp_out;        // [points * V/8, mp_cstride], same channel offsets as `out`
   int mp_cstride;
   int mp_mode;
-  // k^3-tap layers: 1 = the 16 32-row MFMA tiles of a workgroup are (8x,2y,2z) blocks (8^3) / (4x,2y) half-planes of
-  // 4 points (4^3), dealt to the 4 SIMDs as a Latin square so that the tiles a padding tap skips are spread evenly
+  // k^3-tap layers: 1 = the 16 32-row MFMA tiles of a workgroup are (8x,2y,2z) blocks (8^3) / x-lines of the
+  // 8 points (4^3), dealt to the 4 SIMDs as a Latin square so that the tiles a padding tap skips are spread evenly
   // over the matrix pipes (conv.hip: tile_row).  0 = tile t holds rows [32t, 32t+32).
   int remap;
   int8_t tap[kMaxTaps][4];   // dz, dy, dx, -
