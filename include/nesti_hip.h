@@ -71,7 +71,8 @@ typedef struct nesti_model nesti_model_t;
 const char* nesti_last_error(void);
 const char* nesti_version(void);
 
-/* Fill cfg with the trained Nesti-Net command line (train_n_est_w_experts.py:20,62). */
+/* Fill cfg with the published Nesti-Net configuration (3 radii, 8^3 Gaussians, variance 0.0156, 7 experts with the
+ * expert_dict of train_n_est_w_experts.py:62) -- not the argparse defaults of that script (3^3 Gaussians). */
 void nesti_default_config(nesti_config_t* cfg);
 
 /* utils/utils.py:70-95 get_3d_grid_gmm: host arrays w[n^3], mu[n^3*3], sigma[n^3*3]
@@ -176,6 +177,20 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
 int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev,
                   int B, void* ws_dev, size_t ws_bytes, float* normals_out_dev,
                   int32_t* expert_out_dev, float* probs_out_dev, void* stream);
+
+/* The body of the reference's predict loop for ONE shape in one call (test_n_est_w_experts.py:129-152 with
+ * utils/pcpnet_dataset.py:286-343 behind the data loader): search grid (when build_grid != 0; replaces the cKDTree of
+ * utils/pcpnet_dataset.py:37) + ball query + MuPS + gating + routed expert for patch rows
+ * [query_row0, query_row0 + M) of the cloud (query_idx_dev / r_abs / seed / grid_ws_dev as in nesti_patches_query),
+ * `batch` queries at a time.  The patch tensors only ever live in ws_dev
+ * (nesti_estimate_workspace_bytes(m, batch) bytes).  Outputs as nesti_forward: [M,3], [M], [M,E]. */
+size_t nesti_estimate_workspace_bytes(const nesti_model_t* m, int batch);
+int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N,
+                           const int32_t* query_idx_dev, int M, const double* r_abs, uint64_t seed,
+                           int query_row0, int batch, int build_grid, void* grid_ws_dev,
+                           size_t grid_ws_bytes, void* ws_dev, size_t ws_bytes,
+                           float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev,
+                           void* stream);
 
 /* ---- text I/O of the file seam (host only) ------------------------------------------------
  * np.loadtxt(<shape>.xyz).astype('float32') (utils/pcpnet_dataset.py:250): call with out == NULL for

@@ -29,7 +29,11 @@ class CConfig(ctypes.Structure):
 
 @dataclass
 class NestiConfig:
-    """Defaults = the trained Nesti-Net command line (train_n_est_w_experts.py:20-64)."""
+    """Defaults = the PUBLISHED Nesti-Net configuration BASELINE.json and SURVEY.md 8(d) name (radii 0.01/0.03/0.05,
+    8^3 Gaussians, variance 0.0156 -- the '--num_gaussians 8' setting train_n_est_w_experts.py:55 recommends, with
+    num_point 512, 7 experts and the expert_dict of :59-62).  They are NOT the argparse defaults of the training
+    script (radii 0.005/0.01/0.03, num_gaussians 3, variance 0.111, train_n_est_w_experts.py:48,55-56); a trained
+    model's values come from its parameters.p (tf_ckpt.load_reference_model)."""
     patch_radius: List[float] = field(default_factory=lambda: [0.01, 0.03, 0.05])
     num_point: int = 512
     n_gaussians: int = 8          # per axis
@@ -54,8 +58,9 @@ class NestiConfig:
 
     @staticmethod
     def for_model(name):
-        """The command-line defaults of the reference's training scripts for ``--model name``
-        (train_n_est_w_experts.py:20-64, train_n_est.py, train_n_est_w_switching.py:20)."""
+        """The configuration this build uses for ``--model name`` when no parameters.p is given: the 8^3-grid setting
+        above, with the scale count each model takes (ss_norm_est one radius, ms_sw_n_est exactly two,
+        models/ms_sw_n_est.py:50).  These are not the argparse defaults of the reference's training scripts."""
         if name == "experts_n_est":
             return NestiConfig()
         if name == "ss_norm_est":
@@ -95,11 +100,12 @@ class NestiConfig:
 
     def to_json(self):
         d = dict(self.__dict__)
-        d["expert_dict"] = {str(k): v for k, v in self.expert_dict.items()}
+        d["expert_dict"] = None if self.expert_dict is None else {str(k): v for k, v in self.expert_dict.items()}
         return json.dumps(d)
 
     @staticmethod
     def from_json(s):
         d = json.loads(s)
-        d["expert_dict"] = {int(k): v for k, v in d["expert_dict"].items()}
+        if d.get("expert_dict") is not None:
+            d["expert_dict"] = {int(k): v for k, v in d["expert_dict"].items()}
         return NestiConfig(**d)

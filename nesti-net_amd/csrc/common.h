@@ -77,8 +77,8 @@ uint16_t host_f32_to_bf16(float f);
 uint16_t host_f32_to_f16(float f);
 
 // ---- optional kernel timing (model.hip) -----------------------------------------
-void prof_begin(int category, hipStream_t st);
-void prof_end(int category, hipStream_t st);
+int prof_begin(int category, hipStream_t st);              // returns a token for prof_end (-1: nothing recorded)
+void prof_end(int category, int token, hipStream_t st);
 
 // ---- launchers implemented in the .hip files -------------------------------
 // embed4: 3^3 grid only -- write rows in a 4^3 index space (64 rows per point, dead rows zero) for the conv towers

@@ -518,14 +518,18 @@ constexpr size_t lds_bytes() {
 
 template <int DT, int TN, bool KPIPE>
 int launch_one(const ConvParams& p, hipStream_t stream) {
-  static bool attr_set = false;
+  // the dynamic-LDS opt-in is a per-device function attribute: one flag per device, not per process
+  constexpr int kMaxDevices = 64;
+  static bool attr_set[kMaxDevices] = {};
+  int dev = 0;
+  NESTI_CHECK_HIP(hipGetDevice(&dev));
   constexpr size_t lds = lds_bytes<TN, KPIPE>();
   static_assert(lds <= 163840, "LDS budget");
   static_assert(!KPIPE || lds >= (size_t)kTileM * kPoolStride + 16, "pooling tile + zero slot must fit");
-  if (!attr_set) {
+  if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
     NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN, KPIPE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
   }
   const int groups = (p.m_tiles + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * p.n_tiles)), block(kThreads);

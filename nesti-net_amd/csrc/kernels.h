@@ -49,8 +49,9 @@ struct ConvParams {
 };
 
 int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream);
-// multi-tap layers with 128-column tiles whose weights are packed fragment-major (conv_taps.hip)
-int launch_conv_taps(const ConvParams& p, int dtype, hipStream_t stream);
+// k^3 taps (k = 3, 5) on the 8^3 volume, four points per workgroup (conv8.hip): p.m_tiles = groups of 4 points,
+// p.n_tiles = 32-column tiles, p.n_chunks = 64-byte K chunks, weights packed [n tile][chunk][tap][32][64 B]
+int launch_conv8(const ConvParams& p, int dtype, int k, hipStream_t stream);
 
 struct PoolParams {
   const void* in;

@@ -5,9 +5,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -32,6 +34,7 @@ struct ProfState {
   long long launches[NESTI_PROF_CATEGORIES] = {0};
 };
 static ProfState g_prof;
+static std::mutex g_prof_mu;   // forward calls may come from several host threads (one stream each)
 
 static hipEvent_t prof_event() {
   if (!g_prof.pool.empty()) { hipEvent_t e = g_prof.pool.back(); g_prof.pool.pop_back(); return e; }
@@ -39,17 +42,29 @@ static hipEvent_t prof_event() {
   (void)hipEventCreate(&e);
   return e;
 }
-void prof_begin(int cat, hipStream_t st) {
-  if (!g_prof.on) return;
+// A stream that is being captured into a hipGraph records nothing: events captured into a graph cannot be
+// synchronised on or timed afterwards.
+static bool prof_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return cs != hipStreamCaptureStatusNone;
+}
+// prof_begin returns a token for prof_end (-1: nothing recorded)
+int prof_begin(int cat, hipStream_t st) {
+  if (!g_prof.on || prof_capturing(st)) return -1;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   hipEvent_t a = prof_event(), b = prof_event();
   (void)hipEventRecord(a, st);
   g_prof.spans[cat].push_back({a, b});
+  return (int)g_prof.spans[cat].size() - 1;
 }
-void prof_end(int cat, hipStream_t st) {
-  if (!g_prof.on) return;
-  (void)hipEventRecord(g_prof.spans[cat].back().second, st);
+void prof_end(int cat, int token, hipStream_t st) {
+  if (token < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (token < (int)g_prof.spans[cat].size()) (void)hipEventRecord(g_prof.spans[cat][token].second, st);
 }
 static void prof_collect() {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   for (int c = 0; c < NESTI_PROF_CATEGORIES; ++c) {
     for (auto& sp : g_prof.spans[c]) {
       (void)hipEventSynchronize(sp.second);
@@ -386,7 +401,7 @@ struct PackedLayer {
   void* wpk = nullptr;
   float* bias = nullptr;
   int TN = 64, n_tiles = 0, split_tile = 0, n_chunks = 0, n_taps = 0;
-  bool frag_major = false;   // weights in conv_taps_kernel's per-wave fragment order
+  int kind = 0;              // 0: conv_igemm_kernel (conv.hip), 1: conv8_kernel (conv8.hip: 4 points per workgroup)
   int8_t tap[kMaxTaps][4];
 };
 
@@ -469,11 +484,12 @@ int fold_layer(const LayerDesc& d, const std::string& scope, const TensorTable& 
   return 0;
 }
 
-// NESTI_CONV_TAPS=1 routes the multi-tap layers with 128-column tiles to the barrier-free kernel of conv_taps.hip
-// (parity-tested, but measured 12 % slower end to end than conv_igemm_kernel -- DESIGN.md 4.3 -- so it is opt-in)
-bool use_taps_kernel(int n_taps, int TN) {
-  static const int on = [] { const char* e = getenv("NESTI_CONV_TAPS"); return e ? atoi(e) : 0; }();
-  return on && n_taps > 1 && TN == 128;
+// Which layers run on conv8_kernel: the k^3 taps on the 8^3 volume.  NESTI_CONV8 = 0: none (everything on
+// conv_igemm_kernel), 1: the 5^3 layers, 2 (default): the 3^3 layers too.
+bool use_conv8(const LayerDesc& d) {
+  static const int mode = [] { const char* e = getenv("NESTI_CONV8"); return e ? atoi(e) : 2; }();
+  if (d.is_fc || d.log2S != 3 || d.s_real || !d.scope2.empty()) return false;
+  return (d.k == 5 && mode >= 1) || (d.k == 3 && mode >= 2);
 }
 
 int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer* pl) {
@@ -496,9 +512,11 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
         tap_widx.push_back((a * d.k + bb) * d.k + c);
         ++pl->n_taps;
       }
-  const int KC = chunk_elems(dtype);
   const size_t esz = dtype_size(dtype);
-  pl->TN = (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
+  pl->kind = use_conv8(d) ? 1 : 0;
+  const int row_bytes = pl->kind == 1 ? 64 : kRowBytes;   // bytes of one K chunk of one row
+  const int KC = row_bytes / (int)esz;
+  pl->TN = pl->kind == 1 ? 32 : (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
   pl->n_tiles = d.Cout_p / pl->TN;
   pl->split_tile = part_p / pl->TN * (n_parts == 2 ? 1 : n_parts);
   if (n_parts == 1) pl->split_tile = pl->n_tiles;
@@ -507,11 +525,10 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
   if (n_parts == 2 && pl->n_taps != 1) NESTI_FAIL("internal: fused layers must be 1x1x1");
   std::vector<int> inv(d.Cin_p, -1);
   for (int c = 0; c < d.cin; ++c) inv[d.in_pos[c]] = c;
-  const size_t tile_bytes = (size_t)pl->TN * kRowBytes;
+  const size_t tile_bytes = (size_t)pl->TN * row_bytes;
   const size_t total = (size_t)pl->n_tiles * pl->n_chunks * pl->n_taps * tile_bytes;
   std::vector<unsigned char> host(total, 0);
   const int per_slot = 16 / (int)esz;
-  pl->frag_major = n_parts == 1 && use_taps_kernel(pl->n_taps, pl->TN);
   for (int nt = 0; nt < pl->n_tiles; ++nt) {
     const int part = (nt * pl->TN) / part_p;
     const int n_base = nt * pl->TN - part * part_p;    // first real channel of this tile within its part
@@ -529,10 +546,9 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
             const int n = n_base + nl;
             if (n >= d.cout) break;
             const float v = wrow[n] * f.scale[n];
-            // conv_igemm_kernel: LDS image, row nl, 16-B slot XOR-swizzled.  conv_taps_kernel: [column group of 32]
-            // [K-step][lane = 32 * (slot & 1) + column][16 B], one contiguous 1-KiB wave load per K-step.
-            unsigned char* dst = pl->frag_major
-                ? tile + (size_t)(nl >> 5) * 4096 + (size_t)(slot >> 1) * 1024 + (size_t)((slot & 1) * 32 + (nl & 31)) * 16 + within * esz
+            // the kernels' LDS image: row nl, 16-B slot XOR-swizzled (conv8_kernel: 64-B rows, key (row >> 2) & 3)
+            unsigned char* dst = pl->kind == 1
+                ? tile + (size_t)nl * 64 + ((slot ^ ((nl >> 2) & 3)) << 4) + within * esz
                 : tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
             if (dtype == NESTI_F32) memcpy(dst, &v, 4);
             else {
@@ -609,14 +625,14 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S; p.s_real = d.s_real;
       p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
       const long long rows = (long long)rc.NB << (3 * d.log2S);
-      p.m_tiles = (int)((rows + kTileM - 1) / kTileM);
+      p.m_tiles = pl.kind == 1 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
       if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C; p.mp_mode = op.mp_mode; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
-      prof_begin(NESTI_PROF_CONV, rc.stream);
-      const int rcv = pl.frag_major ? launch_conv_taps(p, dtype, rc.stream) : launch_conv(p, dtype, pl.TN, rc.stream);
-      prof_end(NESTI_PROF_CONV, rc.stream);
+      const int tok = prof_begin(NESTI_PROF_CONV, rc.stream);
+      const int rcv = pl.kind == 1 ? launch_conv8(p, dtype, d.k, rc.stream) : launch_conv(p, dtype, pl.TN, rc.stream);
+      prof_end(NESTI_PROF_CONV, tok, rc.stream);
       if (rcv) return 1;
     } else {
       PoolParams p;
@@ -627,9 +643,9 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.in_cstride = T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
       p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
       p.C = op.C; p.log2S = op.log2S;
-      prof_begin(NESTI_PROF_POOL, rc.stream);
+      const int tok = prof_begin(NESTI_PROF_POOL, rc.stream);
       const int rcp = op.kind == Op::MAX3 ? launch_maxpool3s2(p, dtype, rc.stream) : launch_maxpool2(p, dtype, rc.stream);
-      prof_end(NESTI_PROF_POOL, rc.stream);
+      prof_end(NESTI_PROF_POOL, tok, rc.stream);
       if (rcp) return 1;
     }
   }
@@ -707,7 +723,7 @@ const char* nesti_version(void) { return "nesti-hip 0.1 (gfx950)"; }
 void nesti_default_config(nesti_config_t* cfg) {
   memset(cfg, 0, sizeof(*cfg));
   cfg->arch = NESTI_ARCH_EXPERTS;
-  cfg->n_scales = 3;                 // --patch_radius 0.01 0.03 0.05   train_n_est_w_experts.py:20
+  cfg->n_scales = 3;                 // --patch_radius 0.01 0.03 0.05 (the published setting; the script default is 0.005 0.01 0.03)
   cfg->points_per_scale = 512;       // --num_point
   cfg->grid_n = 8;                   // --n_gaussians 8
   cfg->variance = 0.0156;            // --gmm_variance
@@ -741,9 +757,9 @@ int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev, const
                        void* out_dev, int out_dtype, int out_cstride, void* stream) {
   if (B <= 0) return 0;   // empty batch: nothing to do
   if (!cfg || !points_dev || !n_eff_dev || !out_dev) NESTI_FAIL("nesti_mups_forward: null argument");
-  prof_begin(NESTI_PROF_MUPS, (hipStream_t)stream);
+  const int tok = prof_begin(NESTI_PROF_MUPS, (hipStream_t)stream);
   const int rc = launch_mups(cfg, points_dev, n_eff_dev, B, out_dev, out_dtype, out_cstride, /*embed4=*/0, (hipStream_t)stream);
-  prof_end(NESTI_PROF_MUPS, (hipStream_t)stream);
+  prof_end(NESTI_PROF_MUPS, tok, (hipStream_t)stream);
   return rc;
 }
 
@@ -800,10 +816,10 @@ int nesti_model_mups(const nesti_model_t* m, const float* points_dev, const int3
                      void* stream) {
   if (B <= 0) return 0;
   if (!m || !points_dev || !n_eff_dev || !mups_out_dev) NESTI_FAIL("nesti_model_mups: null argument");
-  prof_begin(NESTI_PROF_MUPS, (hipStream_t)stream);
+  const int tok = prof_begin(NESTI_PROF_MUPS, (hipStream_t)stream);
   const int rc = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, mups_out_dev, m->dtype, m->graph.mups_cstride,
                              /*embed4=*/m->graph.cfg.grid_n == 3, (hipStream_t)stream);
-  prof_end(NESTI_PROF_MUPS, (hipStream_t)stream);
+  prof_end(NESTI_PROF_MUPS, tok, (hipStream_t)stream);
   return rc;
 }
 
@@ -851,10 +867,10 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   unsigned char* ws = (unsigned char*)ws_dev;
   hipStream_t st = (hipStream_t)stream;
   void* X0 = ws + L.x0;
-  prof_begin(NESTI_PROF_MUPS, st);
+  const int tok = prof_begin(NESTI_PROF_MUPS, st);
   const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride,
                               /*embed4=*/m->graph.cfg.grid_n == 3, st);
-  prof_end(NESTI_PROF_MUPS, st);
+  prof_end(NESTI_PROF_MUPS, tok, st);
   if (rcm) return 1;
   if (m->graph.cfg.arch == NESTI_ARCH_SINGLE || m->graph.cfg.arch == NESTI_ARCH_MULTI)   // single-tower ablations: the tower's output IS n_pred (test_n_est.py:136-141)
     return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, nullptr, nullptr, normals_out_dev, st);
@@ -864,6 +880,50 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   int32_t* lists = (int32_t*)(ws + L.lists);
   if (gate_impl(m, X0, B, ws + L.tower, L.total - L.tower, probs, expert, counts, lists, st)) return 1;
   return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
+}
+
+// ---- fused end-to-end entry: search grid + ball query + MuPS + gate + routed experts, batch by batch ---------------
+static size_t est_points_bytes(const nesti_model* m, int batch) {
+  return align_up((size_t)batch * m->graph.cfg.n_scales * m->graph.cfg.points_per_scale * 3 * sizeof(float), 256);
+}
+static size_t est_neff_bytes(const nesti_model* m, int batch) {
+  return align_up((size_t)batch * m->graph.cfg.n_scales * sizeof(int32_t), 256);
+}
+
+size_t nesti_estimate_workspace_bytes(const nesti_model_t* m, int batch) {
+  if (!m || batch <= 0) return 0;
+  return est_points_bytes(m, batch) + est_neff_bytes(m, batch) + ws_layout(m, batch).total;
+}
+
+int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N, const int32_t* query_idx_dev, int M,
+                           const double* r_abs, uint64_t seed, int query_row0, int batch, int build_grid,
+                           void* grid_ws_dev, size_t grid_ws_bytes, void* ws_dev, size_t ws_bytes,
+                           float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, void* stream) {
+  if (!m || !cloud_dev || !r_abs || !grid_ws_dev || !ws_dev || !normals_out_dev)
+    NESTI_FAIL("nesti_estimate_normals: null argument");
+  if (N <= 0) NESTI_FAIL("nesti_estimate_normals: empty cloud");
+  if (batch <= 0) NESTI_FAIL("nesti_estimate_normals: batch must be positive");
+  if (nesti_estimate_workspace_bytes(m, batch) > ws_bytes)
+    NESTI_FAIL("nesti_estimate_normals: workspace too small (see nesti_estimate_workspace_bytes)");
+  const nesti_config_t* cfg = &m->graph.cfg;
+  unsigned char* ws = (unsigned char*)ws_dev;
+  float* points = (float*)ws;
+  int32_t* n_eff = (int32_t*)(ws + est_points_bytes(m, batch));
+  unsigned char* fwd_ws = ws + est_points_bytes(m, batch) + est_neff_bytes(m, batch);
+  const size_t fwd_bytes = ws_layout(m, batch).total;
+  if (build_grid && nesti_patches_grid(cfg, cloud_dev, N, r_abs, grid_ws_dev, grid_ws_bytes, stream)) return 1;
+  const int E = m->graph.cfg.arch == NESTI_ARCH_SWITCH ? 1 : m->graph.cfg.n_experts;   // columns of probs_out
+  for (int done = 0; done < M; done += batch) {
+    const int take = std::min(batch, M - done);
+    if (nesti_patches_query(cfg, cloud_dev, N, query_idx_dev ? query_idx_dev + done : nullptr, take, r_abs, seed,
+                            query_row0 + done, points, n_eff, nullptr, nullptr, grid_ws_dev, grid_ws_bytes, stream))
+      return 1;
+    if (nesti_forward(m, points, n_eff, take, fwd_ws, fwd_bytes, normals_out_dev + (size_t)done * 3,
+                      expert_out_dev ? expert_out_dev + done : nullptr,
+                      probs_out_dev ? probs_out_dev + (size_t)done * E : nullptr, stream))
+      return 1;
+  }
+  return 0;
 }
 
 int nesti_profile_enable(int on) {

@@ -177,7 +177,7 @@ struct PatchParams {
   const int* start;
   const GridHeader* header;
   const int32_t* query_idx;
-  int M, S, P, row0;
+  int M, N, S, P, row0;
   unsigned long long seed;
   double r2[NESTI_MAX_SCALES];     // r*r, like cKDTree's upper_bound for p = 2
   float rad_f[NESTI_MAX_SCALES];   // (float)r : torch divides the f32 patch by the scalar in f32
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(kThreads) void patches_kernel(const PatchParams p) 
 
   const int q = blockIdx.x;
   const int t = threadIdx.x;
-  const int qi = p.query_idx ? p.query_idx[q] : p.row0 + q;   // 'full' sampler: patch row == point index
+  int qi = p.query_idx ? p.query_idx[q] : p.row0 + q;         // 'full' sampler: patch row == point index
+  qi = min(max(qi, 0), p.N - 1);
   const GridHeader h = *p.header;
   const float cxf = p.cloud[(size_t)qi * 3], cyf = p.cloud[(size_t)qi * 3 + 1], czf = p.cloud[(size_t)qi * 3 + 2];
   const double cx = cxf, cy = cyf, cz = czf;
@@ -358,6 +359,12 @@ int nesti_patches_query(const nesti_config_t* cfg, const float* cloud_dev, int N
   const WsLayout L = ws_layout(N);
   if (grid_ws_bytes < L.total) NESTI_FAIL("nesti_patches_query: grid workspace too small");
   if (M <= 0) return 0;
+  // 'full' sampler (query_idx NULL): patch row == point index, so the row range must lie inside the cloud.  With a
+  // query list the indices live on the device; the host mirror (provider.CloudPatches) validates them once at upload
+  // and the kernel clamps defensively (a bad index then yields a wrong patch, never an out-of-bounds read).
+  if (query_row0 < 0) NESTI_FAIL("nesti_patches_query: query_row0 must be >= 0");
+  if (!query_idx_dev && (long long)query_row0 + M > (long long)N)
+    NESTI_FAIL("nesti_patches_query: query rows [query_row0, query_row0 + M) exceed the cloud (N points)");
   const unsigned char* ws = (const unsigned char*)grid_ws_dev;
   PatchParams p;
   memset(&p, 0, sizeof(p));
@@ -366,16 +373,16 @@ int nesti_patches_query(const nesti_config_t* cfg, const float* cloud_dev, int N
   p.start = (const int*)(ws + L.start);
   p.header = (const GridHeader*)(ws + L.header);
   p.query_idx = query_idx_dev;
-  p.M = M; p.S = cfg->n_scales; p.P = cfg->points_per_scale; p.seed = seed; p.row0 = query_row0;
+  p.M = M; p.N = N; p.S = cfg->n_scales; p.P = cfg->points_per_scale; p.seed = seed; p.row0 = query_row0;
   for (int s = 0; s < cfg->n_scales; ++s) {
     if (!(r_abs[s] > 0.0)) NESTI_FAIL("nesti_patches_query: radii must be positive");
     p.r2[s] = r_abs[s] * r_abs[s];
     p.rad_f[s] = (float)r_abs[s];
   }
   p.points_out = points_out_dev; p.n_eff_out = n_eff_out_dev; p.nbr_out = nbr_idx_out_dev; p.n_ball_out = n_ball_out_dev;
-  prof_begin(NESTI_PROF_PATCHES, (hipStream_t)stream);
+  const int tok = prof_begin(NESTI_PROF_PATCHES, (hipStream_t)stream);
   hipLaunchKernelGGL(patches_kernel, dim3(M), dim3(kThreads), 0, (hipStream_t)stream, p);
-  prof_end(NESTI_PROF_PATCHES, (hipStream_t)stream);
+  prof_end(NESTI_PROF_PATCHES, tok, (hipStream_t)stream);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

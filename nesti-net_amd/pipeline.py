@@ -2,9 +2,12 @@
 query) -> MuPS -> gating -> top-1 expert -> normals.  This is the body of the reference's
 ``predict`` loop (``test_n_est_w_experts.py:129-152``) with the per-point Python
 ``__getitem__`` and the TF ``sess.run`` replaced by three library calls per batch."""
+import ctypes
+
 import numpy as np
 import torch
 
+from . import _lib
 from .config import ARCH_MULTI, ARCH_SINGLE, NestiConfig
 from .model import NestiNet
 from .provider import CloudPatches
@@ -18,18 +21,27 @@ class NormalEstimator:
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", batch=4096, seed=3627473,
                  use_graph=False, n_streams=1):
         self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
-        self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=self.batch)
-        S, P, E = cfg.n_scales, cfg.num_point, max(1, cfg.n_gate_out)
-        self._points = torch.empty((self.batch, S * P, 3), dtype=torch.float32, device=self.device)
-        self._n_eff = torch.empty((self.batch, S), dtype=torch.int32, device=self.device)
+        self.use_graph = bool(use_graph)
         # n_streams > 1: consecutive batches alternate between HIP streams (own staging buffers and scratch
         # arena each), so one batch's partially filled last workgroup rounds overlap the other's kernels
         self.n_streams = 1 if use_graph else max(1, int(n_streams))
+        # plain mode (one stream, no graph): ONE library call per run (nesti_estimate_normals) on one arena that holds
+        # the patch staging buffers and the forward workspace; the graph / multi-stream modes drive the batches from here
+        self._fused = not self.use_graph and self.n_streams == 1
+        self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=1 if self._fused else self.batch)
+        S, P, E = cfg.n_scales, cfg.num_point, max(1, cfg.n_gate_out)
+        if self._fused:
+            nbytes = self.net.lib.nesti_estimate_workspace_bytes(self.net._handle, self.batch)
+            self._arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._lanes, self._graph = [], None
+            return
+        self._points = torch.empty((self.batch, S * P, 3), dtype=torch.float32, device=self.device)
+        self._n_eff = torch.empty((self.batch, S), dtype=torch.int32, device=self.device)
         self._lanes = []
         for i in range(1, self.n_streams):
             self._lanes.append((torch.cuda.Stream(device=self.device), torch.empty_like(self._points),
                                 torch.empty_like(self._n_eff), self.net.new_workspace(self.batch)))
-        self.use_graph, self._graph = bool(use_graph), None
+        self._graph = None
         if self.use_graph:
             self._g_out = (torch.empty((self.batch, 3), dtype=torch.float32, device=self.device),
                            torch.empty((self.batch,), dtype=torch.int32, device=self.device),
@@ -69,6 +81,21 @@ class NormalEstimator:
         else:
             normals, expert, probs = out
         single_tower = self.cfg.arch in (ARCH_SINGLE, ARCH_MULTI)      # ss/ms ablations: normals only
+        if first < 0 or count < 0 or first + count > cloud.patch_count:
+            raise ValueError("patch rows [%d, %d) outside [0, %d)" % (first, first + count, cloud.patch_count))
+        if self._fused:
+            qidx = cloud.pidx[first:first + count].contiguous() if cloud.pidx is not None else None
+            st = torch.cuda.current_stream(self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self.net.lib.nesti_estimate_normals(
+                    self.net._handle, _lib.ptr(cloud.cloud), cloud.n_points, _lib.ptr(qidx), count, cloud._r,
+                    ctypes.c_uint64(cloud.seed), first, self.batch, 0, _lib.ptr(cloud._ws), cloud._ws.numel(),
+                    _lib.ptr(self._arena), self._arena.numel(), _lib.ptr(normals),
+                    None if single_tower else _lib.ptr(expert), None if single_tower else _lib.ptr(probs),
+                    ctypes.c_void_p(st.cuda_stream)), "nesti_estimate_normals")
+            if single_tower:
+                return normals, None, None
+            return normals, expert, probs
         done, it = 0, 0
         main = torch.cuda.current_stream(self.device)
         if self.n_streams > 1:

@@ -50,7 +50,11 @@ class CloudPatches:
         self.bbdiag = float(np.linalg.norm(pts.max(0) - pts.min(0), 2))
         self.r_abs = [self.bbdiag * rad for rad in cfg.patch_radius]
         self.cloud = torch.from_numpy(pts).to(self.device)
-        self.pidx = None if pidx is None else torch.as_tensor(np.asarray(pidx), dtype=torch.int32, device=self.device)
+        if pidx is not None:
+            pidx = np.asarray(pidx).astype(np.int64).reshape(-1)
+            if len(pidx) and (pidx.min() < 0 or pidx.max() >= self.n_points):      # a bad .pidx file must not read out of bounds
+                raise ValueError("pidx entries must lie in [0, %d): got [%d, %d]" % (self.n_points, pidx.min(), pidx.max()))
+        self.pidx = None if pidx is None else torch.as_tensor(pidx, dtype=torch.int32, device=self.device)
         self.patch_count = self.n_points if pidx is None else len(pidx)     # :276-279
         nbytes = self.lib.nesti_patches_workspace_bytes(self.n_points)
         self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -75,6 +79,8 @@ class CloudPatches:
         [count,S] when ``want_idx``).  The subsample key uses the global row ``first + i`` so
         results do not depend on batching."""
         S, P = self.cfg.n_scales, self.cfg.num_point
+        if first < 0 or count < 0 or first + count > self.patch_count:
+            raise ValueError("patch rows [%d, %d) outside [0, %d)" % (first, first + count, self.patch_count))
         # sparse: <shape>.pidx rows; full: NULL -> the kernel uses point index = patch row
         qidx = self.pidx[first:first + count].contiguous() if self.pidx is not None else None
         if out is None:

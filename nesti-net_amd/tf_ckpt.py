@@ -17,6 +17,7 @@ import io
 import json
 import os
 import pickle
+import re
 import struct
 
 import numpy as np
@@ -150,20 +151,23 @@ def map_variables(raw, expected):
     ``<scope>/weights|biases`` and ``<scope>/bn/beta|gamma`` are used verbatim
     (``utils/tf_util.py:292,301,473-476``).  The EMA shadows of the batch statistics are named by
     ``tf.train.ExponentialMovingAverage`` after the ``moments`` ops (``utils/tf_util.py:477-479``),
-    so they are discovered: under ``<scope>/bn/`` the two keys ending in
-    ``ExponentialMovingAverage``; the variance is the one whose op name has the ``_1`` / 'variance'
-    suffix."""
+    so they are DISCOVERED in the checkpoint's index rather than spelled here: under ``<scope>/bn/`` the keys whose
+    last component is ``ExponentialMovingAverage`` (or a uniquified ``ExponentialMovingAverage_<n>``); the op name in
+    front of it tells the statistic -- ``tf.nn.moments`` squeezes the mean in ``Squeeze`` and the variance in
+    ``Squeeze_1`` (or names them ``mean`` / ``variance``).  Exactly one of each must exist; anything else raises."""
     out = {}
     for name, shape in expected.items():
         if name in raw:
             arr = raw[name]
         elif name.endswith("/bn/mean") or name.endswith("/bn/var"):
             scope = name[:name.rindex("/")] + "/"
-            cands = sorted(k for k in raw if k.startswith(scope) and k.endswith("ExponentialMovingAverage"))
+            cands = sorted(k for k in raw if k.startswith(scope) and re.search(r"/ExponentialMovingAverage(_\d+)?$", k))
             if len(cands) != 2:
                 raise KeyError("expected 2 EMA shadow variables under %s, found %s" % (scope, cands))
-            is_var = [("Squeeze_1" in k) or ("variance" in k) for k in cands]
-            if sum(is_var) != 1:
+            ops = [k.split("/")[-2] for k in cands]                  # the moments op the shadow belongs to
+            is_var = [op in ("Squeeze_1", "variance") for op in ops]
+            is_mean = [op in ("Squeeze", "mean") for op in ops]
+            if sum(is_var) != 1 or sum(is_mean) != 1:
                 raise KeyError("cannot tell mean from variance among %s" % cands)
             arr = raw[cands[is_var.index(name.endswith("/bn/var"))]]
         else:

@@ -10,6 +10,7 @@ reference's scopes (``<scope>/weights``, ``<scope>/biases``, ``<scope>/bn/beta|g
 ``<scope>/bn/mean`` and ``<scope>/bn/var`` here.
 """
 import ctypes
+import os
 import struct
 from collections import OrderedDict
 
@@ -20,6 +21,7 @@ from .config import NestiConfig
 
 WEIGHT_SEED = 20190615
 MAGIC = b"NSTW1\0\0\0"
+BN_STATS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "synth_bn_stats.npz")
 
 
 def describe(cfg: NestiConfig):
@@ -37,8 +39,14 @@ def describe(cfg: NestiConfig):
     return out
 
 
-def synthetic_weights(cfg: NestiConfig, seed=WEIGHT_SEED):
-    """Deterministic float32 variables for ``cfg``."""
+def synthetic_weights(cfg: NestiConfig, seed=WEIGHT_SEED, bn="auto"):
+    """Deterministic float32 variables for ``cfg``.
+
+    ``bn``: 'random' -- arbitrary batch-norm EMA statistics (exercises the fold, but the activations of the deep ReLU
+    stack are then dominated by their input-independent mean); 'calibrated' -- the EMA statistics a training run would
+    leave behind: per-channel mean / variance of every layer's pre-activation over a sample of real MuPS tensors
+    (``scripts/make_synth_bn_stats.py`` -> ``data/synth_bn_stats.npz``, generated for the default configuration and
+    ``WEIGHT_SEED``); 'auto' -- calibrated when the committed statistics fit this configuration, else random."""
     rng = np.random.RandomState(seed)
     W = OrderedDict()
     for name, shape in describe(cfg).items():
@@ -65,6 +73,19 @@ def synthetic_weights(cfg: NestiConfig, seed=WEIGHT_SEED):
     if "fc4noise/biases" in W:
         W["fc4noise/biases"] = rng.uniform(0.5, 1.5, size=W["fc4noise/biases"].shape).astype(np.float32)
         W["fc4noise/weights"] = (W["fc4noise/weights"] * 4.0).astype(np.float32)
+    if bn not in ("auto", "random", "calibrated"):
+        raise ValueError("bn must be 'auto', 'random' or 'calibrated'")
+    if bn != "random":
+        ok = os.path.exists(BN_STATS_FILE) and seed == WEIGHT_SEED
+        stats = dict(np.load(BN_STATS_FILE)) if ok else {}
+        ok = ok and int(stats.pop("seed")) == seed
+        names = [n for n in W if n.endswith("/bn/mean") or n.endswith("/bn/var")]
+        ok = ok and all(n in stats and stats[n].shape == W[n].shape for n in names) and len(names) == len(stats)
+        if ok:
+            for n in names:
+                W[n] = stats[n].astype(np.float32)
+        elif bn == "calibrated":
+            raise ValueError("no committed batch-norm statistics for this configuration / seed (scripts/make_synth_bn_stats.py)")
     return W
 
 

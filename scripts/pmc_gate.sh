@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the gating tower's conv launches (last repetition) at batch $1; extra env as $2 (e.g. NESTI_CONV_TAPS=0)
+# SQ counters of the gating tower's conv launches (last repetition) at batch $1; extra env as $2 (e.g. NESTI_CONV_REMAP=0)
 cd /tmp && export TMPDIR=/tmp
 B=${1:-2048}
 [ -n "$2" ] && export $2

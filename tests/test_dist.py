@@ -31,6 +31,10 @@ def _worker(rank, world, port, n_rows, q):
     expert = (torch.arange(lo, hi) % 7).to(torch.int32)
     probs = torch.stack([rows + e for e in range(7)], 1)
     n, e, p = nd.gather_shards(normals, expert, probs, n_rows)
+    n1, e1, p1 = nd.gather_shards(normals, None, None, n_rows)        # single-tower models: normals only
+    assert e1 is None and p1 is None and torch.equal(n1, n)
+    n2, e2, p2 = nd.gather_shards(normals, expert, probs, n_rows)     # buffers are reused from shape to shape
+    assert torch.equal(n2, n) and torch.equal(e2, e) and torch.equal(p2, p)
     q.put((rank, n.numpy(), e.numpy(), p.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -47,8 +51,12 @@ def test_shard_ranges_cover_everything():
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
 
 
-def test_gather_two_ranks_gloo():
-    n_rows, world = 1001, 2        # ragged: shards of 500 and 501
+import pytest
+
+
+@pytest.mark.parametrize("n_rows", [1001, 1000])      # ragged (shards of 500 and 501) and equal shards
+def test_gather_two_ranks_gloo(n_rows):
+    world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

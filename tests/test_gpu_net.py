@@ -401,20 +401,6 @@ def test_empty_batch_is_a_no_op(setup, net_f32, gpu_device):
     assert net_f32.mups(p, n).shape[0] == 0
 
 
-def test_barrier_free_tap_kernel_variant_matches_oracle(gpu_device):
-    """conv_taps.hip (opt-in, NESTI_CONV_TAPS=1: per-wave weight fragments from L2, one barrier per channel chunk) is a
-    second implementation of the k^3-tap layers; the switch is read once per process, so the f32 / bf16 oracle
-    comparisons of this file are re-run in a child process with it set."""
-    import os
-    import subprocess
-    import sys
-    env = dict(os.environ, NESTI_CONV_TAPS="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-m", "gpu", "-k",
-                        "f32_forward_top1 or 16bit_modes or switching_model or 3_gaussian"], env=env, capture_output=True,
-                       text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
 def test_error_behaviour_at_the_boundary(setup, net_f32, gpu_device):
     """The C-ABI reports misuse through its status code + nesti_last_error (raised as NestiError by the host mirror)
     instead of faulting: workspace too small, missing or mis-shaped variables, wrong model kind, null pointers."""

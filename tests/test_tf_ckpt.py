@@ -12,80 +12,7 @@ import types
 import numpy as np
 import pytest
 
-
-def _vi(n):
-    out = bytearray()
-    while True:
-        b = n & 0x7f
-        n >>= 7
-        if n:
-            out.append(b | 0x80)
-        else:
-            out.append(b)
-            return bytes(out)
-
-
-def _entry(dtype, shape, offset, size):
-    dims = b"".join(b"\x12" + _vi(len(_vi(d)) + 1) + b"\x08" + _vi(d) for d in shape)      # dim { size }
-    msg = b"\x08" + _vi(dtype) + b"\x12" + _vi(len(dims)) + dims
-    msg += b"\x18" + _vi(0) + b"\x20" + _vi(offset) + b"\x28" + _vi(size) + b"\x35" + struct.pack("<I", 0)
-    return msg
-
-
-def _block(items, restart_interval=16):
-    buf, restarts, prev = bytearray(), [], b""
-    for i, (k, v) in enumerate(items):
-        shared = 0
-        if i % restart_interval == 0:
-            restarts.append(len(buf))
-        else:
-            while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
-                shared += 1
-        buf += _vi(shared) + _vi(len(k) - shared) + _vi(len(v)) + k[shared:] + v
-        prev = k
-    for r in restarts:
-        buf += struct.pack("<I", r)
-    buf += struct.pack("<I", len(restarts))
-    return bytes(buf)
-
-
-def write_bundle(prefix, tensors, per_block=7):
-    """Minimal tensor-bundle writer: uncompressed table, several data blocks, one shard."""
-    data, items = bytearray(), [(b"", b"\x08\x01")]                       # header entry (empty key)
-    for name in sorted(tensors):
-        a = np.ascontiguousarray(tensors[name], dtype=np.float32)
-        items.append((name.encode(), _entry(1, a.shape, len(data), a.nbytes)))
-        data += a.tobytes()
-    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
-    out, index_items = bytearray(), []
-    for i in range(0, len(items), per_block):
-        blk = _block(items[i:i + per_block], restart_interval=3)
-        index_items.append((items[min(i + per_block, len(items)) - 1][0], _vi(len(out)) + _vi(len(blk))))
-        out += blk + b"\x00" + struct.pack("<I", 0)                         # type + crc trailer
-    meta = _block([])
-    meta_h = _vi(len(out)) + _vi(len(meta))
-    out += meta + b"\x00" + struct.pack("<I", 0)
-    idx = _block(index_items, restart_interval=1)
-    idx_h = _vi(len(out)) + _vi(len(idx))
-    out += idx + b"\x00" + struct.pack("<I", 0)
-    footer = (meta_h + idx_h).ljust(40, b"\x00") + struct.pack("<Q", 0xdb4775248b80fb57)
-    open(prefix + ".index", "wb").write(bytes(out) + footer)
-
-
-def _tf_names(W):
-    """Rename this package's variables the way TF1 names them (EMA shadows under the moments op)."""
-    out = {}
-    for k, v in W.items():
-        if k.endswith("/bn/mean"):
-            sc = k[:-len("/mean")]
-            out["%s/%s/moments/Squeeze/ExponentialMovingAverage" % (sc, sc)] = v
-        elif k.endswith("/bn/var"):
-            sc = k[:-len("/var")]
-            out["%s/%s/moments/Squeeze_1/ExponentialMovingAverage" % (sc, sc)] = v
-        else:
-            out[k] = v
-    out["beta1_power"] = np.float32(0.5)                                    # optimizer slots are ignored
-    return out
+from ckpt_writer import tf_names, write_bundle
 
 
 def test_bundle_roundtrip_and_name_mapping(tmp_path):
@@ -100,13 +27,25 @@ def test_bundle_roundtrip_and_name_mapping(tmp_path):
         W["pad%03d/weights" % i] = rng.randn(2, 2).astype(np.float32)
         expected["pad%03d/weights" % i] = (2, 2)
     prefix = str(tmp_path / "model.ckpt")
-    write_bundle(prefix, _tf_names(W))
+    write_bundle(prefix, tf_names(W))
     raw = tf_ckpt.read_bundle(prefix)
     assert "beta1_power" in raw and len(raw) == len(W) + 1
     got = tf_ckpt.map_variables(raw, expected)
     assert set(got) == set(expected)
     for k in expected:
         assert np.array_equal(got[k], W[k]), k
+    # the spelling with re-entered name scopes: <scope>/bn/<scope>/bn_1/moments/Squeeze_1/ExponentialMovingAverage_1
+    prefix_u = str(tmp_path / "model_u.ckpt")
+    named = tf_names(W, uniquified=True)
+    assert any(k.endswith("ExponentialMovingAverage_1") and "/bn_1/" in k for k in named)
+    write_bundle(prefix_u, named)
+    got_u = tf_ckpt.map_variables(tf_ckpt.read_bundle(prefix_u), expected)
+    assert all(np.array_equal(got_u[k], W[k]) for k in expected)
+    # two shadow variables of the same kind under one scope cannot be told apart: an error, not a guess
+    dup = dict(raw)
+    dup["a_conv1/bn/a_conv1/bn_1/moments/Squeeze/ExponentialMovingAverage"] = raw["a_conv1/bn/a_conv1/bn/moments/Squeeze/ExponentialMovingAverage"]
+    with pytest.raises(KeyError):
+        tf_ckpt.map_variables(dup, expected)
     with pytest.raises(KeyError):
         tf_ckpt.map_variables(raw, {"missing/weights": (1,)})
     with pytest.raises(ValueError):
@@ -160,7 +99,7 @@ def test_py2_pickles_and_full_model_dir(tmp_path, monkeypatch):
     monkeypatch.setattr(weights, "describe", lambda c: exp)
     rng = np.random.RandomState(1)
     W = {k: rng.rand(*s).astype(np.float32) for k, s in exp.items()}
-    write_bundle(str(tmp_path / "model.ckpt"), _tf_names(W), per_block=50)
+    write_bundle(str(tmp_path / "model.ckpt"), tf_names(W), per_block=50)
     cfg3, W3 = tf_ckpt.load_reference_model(str(tmp_path) + os.sep)
     assert cfg3 == cfg and list(W3) == list(exp)
     assert all(np.array_equal(W3[k], W[k]) for k in exp)
