@@ -233,11 +233,15 @@ def reference_run(args, cfg, W, cloud_np, dev, world):
     lo, hi = ndist.shard_range(len(cloud_np), 0, world)
     est = NormalEstimator(cfg, W, dtype="f32", device=dev, batch=min(8192, hi - lo))
     cloud = est.prepare(cloud_np)
-    out = [t.cpu().numpy() for t in est.run(cloud, lo, hi - lo)]
     torch.cuda.synchronize(dev)
-    del cloud, est
+    t0 = time.perf_counter()
+    res = est.run(cloud, lo, hi - lo)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    out = [t.cpu().numpy() for t in res]
+    del cloud, est, res
     torch.cuda.empty_cache()
-    return out
+    return out, (hi - lo) / el
 
 
 def main():
@@ -362,9 +366,13 @@ def main():
         ref = None
         if not args.no_parity and args.dtype != "f32":
             from nesti_net_amd import parity
-            ref = reference_run(args, cfg, W, clouds_np[0][0], dev, world)
+            ref, ref_rate = reference_run(args, cfg, W, clouds_np[0][0], dev, world)
             res["parity"] = parity.compare(main_run["shard0"], ref)
             res["parity"]["dtype"] = args.dtype
+            # the exact-fp32 MFMA mode is the one that meets the north star's parity clause (arg-max bit-exact, 1e-5 cosine
+            # against the CPU oracle: tests/test_gpu_fixtures.py); its rate on the same cloud, one untimed-style pass
+            res["exact_mode"] = {"dtype": "f32", "value": ref_rate, "unit": "normals/sec (1 GPU, one pass over rank 0's shard)",
+                                 "peak_tflops": PEAK_TFLOPS["f32"]}
         if second is not None:
             res["secondary"] = {"dtype": "bf16", "value": sum(len(p) for p, _ in clouds_np) * 3 / second["elapsed"],
                                 "unit": "normals/sec", "steps": 3, "warmup": 1, "ms_per_step": 1e3 * second["elapsed"] / 3}

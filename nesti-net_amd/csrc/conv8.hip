@@ -96,9 +96,12 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
     a_voff[h] = (unsigned)((pt * 512 + x) * p.in_cstride * kEsz + kslot * 16);
     a_ok[h] = pt < np_here;
   }
-  auto stage_a = [&](int c) __attribute__((always_inline)) {
+  // tiles (bit j) of this wave whose slots are staged; split so that part of the next chunk can be prefetched while the
+  // current chunk's last taps -- which no longer read those slots -- still run
+  auto stage_a = [&](int c, unsigned tiles) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+      if (!(tiles & (1u << j))) continue;
       const int y = (wave - j) & 7;                      // tile (y, z = j) of this wave
       const unsigned char* src = in_b + (size_t)((j * 64 + y * 8) * p.in_cstride) * kEsz + (size_t)c * 64;
 #pragma unroll
@@ -145,6 +148,19 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
     return ((((wave + dy + dz) & 7) * 8) + dz) * kTileBytes;
   };
 
+  // Taps run dz-major, dy next.  The last dz slab (dz = +LO) reads source planes z' >= LO only, its last row (dy = +LO)
+  // source lines y' >= LO only: this wave's slots with z < LO are free from the start of that slab, those with y < LO
+  // from the start of that row, and the next chunk is staged into them early.  The rest waits for the chunk boundary.
+  unsigned pre_slab = 0, pre_row = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int y = (wave - j) & 7;
+    if (j < LO) pre_slab |= 1u << j;
+    else if (y < LO) pre_row |= 1u << j;
+  }
+  if (!(p.remap & 1)) pre_slab = pre_row = 0;          // A/B switch (NESTI_CONV8_FLAGS bit 0)
+  const unsigned pre_none = 0xffu & ~(pre_slab | pre_row);
+
   f32x16 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
 
   for (int c = 0; c < p.n_chunks; ++c) {
     __syncthreads();                       // every wave is done with the previous chunk
-    stage_a(c);
+    stage_a(c, c == 0 ? 0xffu : pre_none);
     stage_b(c, 0, 0);
     stage_b(c, 1, 1);
     wait_vm0();
@@ -179,6 +195,10 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
     }
     for (int g = 0; g < NG; ++g) {
       if (g + 2 < NG) stage_b(c, g + 2, (g + 2) % 3);
+      if (c + 1 < p.n_chunks) {            // early staging of the next chunk into slots this chunk no longer reads
+        if (g == NG - K) stage_a(c + 1, pre_slab);
+        if (g == NG - 1) stage_a(c + 1, pre_row);
+      }
       const unsigned mask_g = row_mask(g);
       const unsigned mask_n = (g + 1 < NG) ? row_mask(g + 1) : 0u;
       const int base_g = row_base(g);

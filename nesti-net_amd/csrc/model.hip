@@ -630,6 +630,10 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C; p.mp_mode = op.mp_mode; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
+      if (pl.kind == 1) {   // conv8_kernel: feature bits for same-box A/B runs (bit 0: early staging of the next chunk)
+        static const int flags = [] { const char* e = getenv("NESTI_CONV8_FLAGS"); return e ? atoi(e) : 1; }();
+        p.remap = flags;
+      }
       const int tok = prof_begin(NESTI_PROF_CONV, rc.stream);
       const int rcv = pl.kind == 1 ? launch_conv8(p, dtype, d.k, rc.stream) : launch_conv(p, dtype, pl.TN, rc.stream);
       prof_end(NESTI_PROF_CONV, tok, rc.stream);

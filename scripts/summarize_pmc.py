@@ -1,13 +1,29 @@
-"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, csv) into
-profiles/<round>_pmc_traffic.json.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-reports half of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section), so the read
-side is doubled.  Usage: summarize_pmc.py <dir with pmc_FETCH_SIZE/, pmc_WRITE_SIZE/> <queries> <out.json>"""
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, csv) of ONE bench step into
+profiles/<round>_pmc_traffic.json.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of
+the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM section), so the read side is doubled.  Only the timed
+dtype's launches are counted (the gate-calibration probe runs a few f32 launches, template argument 0).
+Usage: summarize_pmc.py <dir with pmc_FETCH_SIZE/, pmc_WRITE_SIZE/> <queries> <out.json> <dtype> <batch>"""
 import collections
 import csv
 import json
+import re
 import sys
 
 root, queries, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+dtype = sys.argv[4] if len(sys.argv) > 4 else "f16"
+batch = int(sys.argv[5]) if len(sys.argv) > 5 else 25000
+DT = {"f32": "0", "bf16": "1", "f16": "2"}[dtype]
+
+
+def family(k):
+    m = re.search(r"(conv8_kernel|conv_igemm_kernel|mups_kernel|maxpool2_kernel)<(\d)", k)
+    if m:
+        if m.group(2) != DT:
+            return None
+        return "conv" if m.group(1).startswith("conv") else m.group(1)
+    if "patches_kernel" in k:
+        return "patches_kernel"
+    return "other"
 
 
 def load(c):
@@ -15,9 +31,9 @@ def load(c):
     for r in csv.DictReader(open("%s/pmc_%s/p_counter_collection.csv" % (root, c))):
         if r["Counter_Name"] != c:
             continue
-        k = r["Kernel_Name"]
-        key = "conv_igemm_kernel" if "conv_igemm" in k else "mups_kernel" if "mups" in k else \
-            "maxpool2_kernel" if "maxpool" in k else "patches_kernel" if "patches_kernel" in k else "other"
+        key = family(r["Kernel_Name"])
+        if key is None:
+            continue
         d[key] += float(r["Counter_Value"])
         n[key] += 1
     return d, n
@@ -25,10 +41,12 @@ def load(c):
 
 f, nf = load("FETCH_SIZE")
 w, nw = load("WRITE_SIZE")
-res = {"queries": queries, "note": "FETCH_SIZE doubled per the gfx950 correction; units KiB -> bytes", "kernels": {}}
+res = {"queries": queries, "dtype": dtype, "batch": batch, "calibrated_gate": True,
+       "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity --no-secondary under rocprofv3 --pmc",
+       "note": "FETCH_SIZE doubled per the gfx950 correction; units KiB -> bytes; 'conv' = conv8_kernel + conv_igemm_kernel", "kernels": {}}
 for k in sorted(set(f) | set(w)):
     rd, wr = 2.0 * f[k] * 1024, w[k] * 1024
     res["kernels"][k] = {"launches": nf[k], "hbm_read_bytes": rd, "hbm_write_bytes": wr,
                          "hbm_bytes_per_launch": (rd + wr) / max(1, nf[k]), "hbm_bytes_per_query": (rd + wr) / queries}
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res["kernels"]["conv_igemm_kernel"]))
+print(json.dumps(res["kernels"].get("conv")))

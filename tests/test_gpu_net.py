@@ -117,7 +117,12 @@ def test_explicit_routing_to_every_expert(setup, net_f32, gpu_device):
     assert torch.equal(routed, sel)
 
 
-@pytest.mark.parametrize("dtype,cos_tol,prob_tol", [("bf16", 2e-3, 5e-2), ("f16", 5e-5, 1e-2)])
+# Sanity bounds on 16 queries with the data-matched batch-norm statistics (weights.synthetic_weights bn='calibrated': every
+# layer's pre-activation is zero-mean / unit-variance over the data, as after training, so rounding noise is measured
+# against a signal of realistic size; with arbitrary statistics the network output barely depends on the query and a
+# 16-bit run agrees with fp32 to 1e-6 for the wrong reason).  The distribution over 10k queries is asserted in
+# tests/test_gpu_fixtures.py::test_production_dtype_parity_on_10k_queries.
+@pytest.mark.parametrize("dtype,cos_tol,prob_tol", [("bf16", 1e-1, 4e-1), ("f16", 5e-3, 6e-2)])
 def test_16bit_modes_close_to_oracle(setup, oracle_out, gpu_device, dtype, cos_tol, prob_tol):
     from nesti_net_amd.model import NestiNet
     cfg, W, pts, n_eff = setup

@@ -232,3 +232,56 @@ def test_full_size_cloud_batching_and_sharding_invariance(gpu_device):
     assert bool(torch.isfinite(na).all()) and bool(torch.isfinite(pa).all())
     hist = torch.bincount(ea.long(), minlength=7)
     assert int((hist > 1000).sum()) == 7, hist.tolist()
+
+
+def test_config4_stream_of_32_clouds_graph_matches_eager(gpu_device):
+    """BASELINE config 4 at its stated size: 32 clouds of 50k-100k points (PCPNet noise levels, gradient / striped
+    density sets, the bench's make_clouds(stream=True) recipe) in flight back to back through the f16 hipGraph path --
+    full batches replay the captured forward, ragged tails run eagerly on the same workspace -- must equal the eager
+    path bit for bit on every cloud; and reference-captured fixture rows routed through a graph replay must match the
+    fp64 oracle within f16's stated bounds (arg-max unless the oracle's top-2 margin is inside the dtype's probability
+    error, normals within 1e-3 cosine; tests/test_gpu_fixtures.py holds the distribution)."""
+    import bench
+    from conftest import golden_patch_files, load_golden_patches
+    from nesti_net_amd import weights
+    from nesti_net_amd.calibrate import calibrate_gate
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.pipeline import NormalEstimator
+    from nesti_net_amd.provider import CloudPatches
+    from oracle import mups_ref, net_ref, patches_ref
+    cfg = NestiConfig()
+    clouds = [p for p, _ in bench.make_clouds(32, 100000, stream=True)]
+    assert min(len(c) for c in clouds) >= 50000 and max(len(c) for c in clouds) <= 100000
+    cp = CloudPatches(clouds[0], cfg, device=gpu_device)
+    sp, sn = cp.build(0, 512)
+    W = calibrate_gate(cfg, weights.synthetic_weights(cfg), sp, sn, device=gpu_device)
+    del cp, sp, sn
+    B = 8192
+    graphed = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=B, use_graph=True)
+    prepared = [graphed.prepare(c) for c in clouds]
+    outs = [graphed.run(pc) for pc in prepared]                      # 32 clouds enqueued back to back, no host sync
+    torch.cuda.synchronize()
+    outs = [[t.cpu().numpy() for t in o] for o in outs]
+    eager = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=B)
+    seen = np.zeros(7, np.int64)
+    for k, pc in enumerate(prepared):
+        n_e, e_e, p_e = [t.cpu().numpy() for t in eager.run(pc)]
+        assert np.array_equal(outs[k][1], e_e), "routing differs on cloud %d" % k
+        assert np.array_equal(outs[k][0], n_e) and np.array_equal(outs[k][2], p_e), "cloud %d" % k
+        assert np.all(np.isfinite(n_e))
+        seen += np.bincount(e_e, minlength=7)
+    assert np.all(seen > 1000), seen
+    # fixture rows through a graph replay: one full batch whose first rows are the reference-captured queries
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid100k" in p][0])
+    fq = g["queries"].astype(np.int64)
+    q = np.concatenate([fq, np.arange(B - len(fq)) * 11 % 100000])
+    n_g, e_g, p_g = graphed.estimate(g["pts"], pidx=q)
+    o_pts, o_neff, _, _ = patches_ref.extract_patches(g["pts"], fq, g["r_abs"], cfg.num_point, g["seed"])
+    ref = net_ref.moe_forward(mups_ref.mups_assemble(o_pts, o_neff, 3), W, dtype=torch.float64, top1_only=True)
+    srt = np.sort(ref["probs"].numpy(), axis=1)
+    margin = srt[:, -1] - srt[:, -2]
+    agree = e_g[:len(fq)] == ref["expert"].numpy()
+    assert np.all(agree | (margin < 0.06))
+    a, b = n_g[:len(fq)][agree].astype(np.float64), ref["normals"].numpy()[agree]
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert np.all(1 - cos < 1e-3)
