@@ -7,7 +7,7 @@ import os
 from .config import CConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnesti_hip.so")
+LIB_PATH = os.environ.get("NESTI_LIB") or os.path.join(_HERE, "libnesti_hip.so")   # NESTI_LIB: another build of the same library (A/B runs)
 
 
 class CTensor(ctypes.Structure):

@@ -85,4 +85,9 @@ void prof_end(int category, int token, hipStream_t st);
 int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n_eff, int B,
                 void* out, int out_dtype, int out_cstride, int embed4, hipStream_t stream);
 
+// ball query + subsample + MuPS in one kernel (mups.hip: patches_mups_kernel); 8^3 grid.  n_eff_out_dev may be NULL.
+int launch_patches_mups(const nesti_config_t* cfg, const float* cloud_dev, int N, const int32_t* query_idx_dev, int M,
+                        const double* r_abs, uint64_t seed, int query_row0, const void* grid_ws_dev, void* out, int out_dtype,
+                        int out_cstride, int32_t* n_eff_out_dev, hipStream_t stream);
+
 }  // namespace nesti

@@ -861,21 +861,9 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
   return experts_impl(m, mups_dev, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
 }
 
-int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B, void* ws_dev,
-                  size_t ws_bytes, float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, void* stream) {
-  if (B <= 0) return 0;   // empty batch: nothing to do
-  if (!m || !points_dev || !n_eff_dev || !ws_dev || !normals_out_dev) NESTI_FAIL("nesti_forward: null argument");
-  if (B <= 0) return 0;
-  const WsLayout L = ws_layout(m, B);
-  if (L.total > ws_bytes) NESTI_FAIL("nesti_forward: workspace too small (see nesti_workspace_bytes)");
-  unsigned char* ws = (unsigned char*)ws_dev;
-  hipStream_t st = (hipStream_t)stream;
-  void* X0 = ws + L.x0;
-  const int tok = prof_begin(NESTI_PROF_MUPS, st);
-  const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride,
-                              /*embed4=*/m->graph.cfg.grid_n == 3, st);
-  prof_end(NESTI_PROF_MUPS, tok, st);
-  if (rcm) return 1;
+// gate -> routing -> experts on a MuPS tensor X0 that already sits in the workspace
+static int forward_tail(const nesti_model_t* m, const void* X0, int B, unsigned char* ws, const WsLayout& L,
+                        float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, hipStream_t st) {
   if (m->graph.cfg.arch == NESTI_ARCH_SINGLE || m->graph.cfg.arch == NESTI_ARCH_MULTI)   // single-tower ablations: the tower's output IS n_pred (test_n_est.py:136-141)
     return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, nullptr, nullptr, normals_out_dev, st);
   float* probs = probs_out_dev ? probs_out_dev : (float*)(ws + L.probs);
@@ -886,8 +874,28 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
 }
 
+int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B, void* ws_dev,
+                  size_t ws_bytes, float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, void* stream) {
+  if (B <= 0) return 0;   // empty batch: nothing to do
+  if (!m || !points_dev || !n_eff_dev || !ws_dev || !normals_out_dev) NESTI_FAIL("nesti_forward: null argument");
+  const WsLayout L = ws_layout(m, B);
+  if (L.total > ws_bytes) NESTI_FAIL("nesti_forward: workspace too small (see nesti_workspace_bytes)");
+  unsigned char* ws = (unsigned char*)ws_dev;
+  hipStream_t st = (hipStream_t)stream;
+  void* X0 = ws + L.x0;
+  const int tok = prof_begin(NESTI_PROF_MUPS, st);
+  const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride,
+                              /*embed4=*/m->graph.cfg.grid_n == 3, st);
+  prof_end(NESTI_PROF_MUPS, tok, st);
+  if (rcm) return 1;
+  return forward_tail(m, X0, B, ws, L, normals_out_dev, expert_out_dev, probs_out_dev, st);
+}
+
 // ---- fused end-to-end entry: search grid + ball query + MuPS + gate + routed experts, batch by batch ---------------
+// 8^3 Gaussian grid: patches_mups_kernel goes from the cloud to the MuPS tensor in one kernel (the patch tensors are never
+// written); 3^3 grid: patches_kernel + mups3_kernel through a staging buffer in the workspace.
 static size_t est_points_bytes(const nesti_model* m, int batch) {
+  if (m->graph.cfg.grid_n == 8) return 0;
   return align_up((size_t)batch * m->graph.cfg.n_scales * m->graph.cfg.points_per_scale * 3 * sizeof(float), 256);
 }
 static size_t est_neff_bytes(const nesti_model* m, int batch) {
@@ -907,25 +915,43 @@ int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N
     NESTI_FAIL("nesti_estimate_normals: null argument");
   if (N <= 0) NESTI_FAIL("nesti_estimate_normals: empty cloud");
   if (batch <= 0) NESTI_FAIL("nesti_estimate_normals: batch must be positive");
+  if (M <= 0) return 0;
+  if (query_row0 < 0 || (!query_idx_dev && (long long)query_row0 + M > (long long)N))
+    NESTI_FAIL("nesti_estimate_normals: query rows [query_row0, query_row0 + M) exceed the cloud (N points)");
   if (nesti_estimate_workspace_bytes(m, batch) > ws_bytes)
     NESTI_FAIL("nesti_estimate_normals: workspace too small (see nesti_estimate_workspace_bytes)");
+  if (grid_ws_bytes < nesti_patches_workspace_bytes(N)) NESTI_FAIL("nesti_estimate_normals: grid workspace too small");
   const nesti_config_t* cfg = &m->graph.cfg;
+  for (int s = 0; s < cfg->n_scales; ++s)
+    if (!(r_abs[s] > 0.0)) NESTI_FAIL("nesti_estimate_normals: radii must be positive");
+  hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)ws_dev;
   float* points = (float*)ws;
   int32_t* n_eff = (int32_t*)(ws + est_points_bytes(m, batch));
   unsigned char* fwd_ws = ws + est_points_bytes(m, batch) + est_neff_bytes(m, batch);
-  const size_t fwd_bytes = ws_layout(m, batch).total;
+  const WsLayout L = ws_layout(m, batch);
   if (build_grid && nesti_patches_grid(cfg, cloud_dev, N, r_abs, grid_ws_dev, grid_ws_bytes, stream)) return 1;
   const int E = m->graph.cfg.arch == NESTI_ARCH_SWITCH ? 1 : m->graph.cfg.n_experts;   // columns of probs_out
+  const bool fused = cfg->grid_n == 8;
   for (int done = 0; done < M; done += batch) {
     const int take = std::min(batch, M - done);
-    if (nesti_patches_query(cfg, cloud_dev, N, query_idx_dev ? query_idx_dev + done : nullptr, take, r_abs, seed,
-                            query_row0 + done, points, n_eff, nullptr, nullptr, grid_ws_dev, grid_ws_bytes, stream))
-      return 1;
-    if (nesti_forward(m, points, n_eff, take, fwd_ws, fwd_bytes, normals_out_dev + (size_t)done * 3,
-                      expert_out_dev ? expert_out_dev + done : nullptr,
-                      probs_out_dev ? probs_out_dev + (size_t)done * E : nullptr, stream))
-      return 1;
+    const int32_t* qidx = query_idx_dev ? query_idx_dev + done : nullptr;
+    float* n_out = normals_out_dev + (size_t)done * 3;
+    int32_t* e_out = expert_out_dev ? expert_out_dev + done : nullptr;
+    float* p_out = probs_out_dev ? probs_out_dev + (size_t)done * E : nullptr;
+    if (fused) {
+      const int tok = prof_begin(NESTI_PROF_MUPS, st);
+      const int rcf = launch_patches_mups(cfg, cloud_dev, N, qidx, take, r_abs, seed, query_row0 + done, grid_ws_dev,
+                                          fwd_ws + L.x0, m->dtype, m->graph.mups_cstride, n_eff, st);
+      prof_end(NESTI_PROF_MUPS, tok, st);
+      if (rcf) return 1;
+      if (forward_tail(m, fwd_ws + L.x0, take, fwd_ws, L, n_out, e_out, p_out, st)) return 1;
+    } else {
+      if (nesti_patches_query(cfg, cloud_dev, N, qidx, take, r_abs, seed, query_row0 + done, points, n_eff, nullptr, nullptr,
+                              grid_ws_dev, grid_ws_bytes, stream))
+        return 1;
+      if (nesti_forward(m, points, n_eff, take, fwd_ws, L.total, n_out, e_out, p_out, stream)) return 1;
+    }
   }
   return 0;
 }

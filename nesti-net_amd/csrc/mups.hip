@@ -14,6 +14,7 @@
 // produced by 192 threads into LDS, then every thread sweeps the chunk with
 // broadcast ds_read_b128s.  The kernel is fp32-VALU bound.
 #include "common.h"
+#include "patches_dev.h"
 
 namespace nesti {
 
@@ -142,135 +143,136 @@ __device__ __forceinline__ void finish(const Stats1& s, int nrows, bool has_mask
   for (int c = 0; c < 20; ++c) v[c] = signed_sqrt(v[c] / m_f);   // :727-735
 }
 
-template <int DT>
-__global__ __launch_bounds__(kThreads) void mups_kernel(const float* __restrict__ points,
-                                                        const int32_t* __restrict__ n_eff, int B,
-                                                        int S, int P, void* __restrict__ out,
-                                                        int cstride, float sigma, float w) {
-  // per staged point: x axis as 4 pairs (i, i+4) laid out for packed math: {q_i, q_i+4, d_i, d_i+4} and
-  // {e_i, e_i+4, -, -}; y and z axes as {q, d, d^2-1, -} per grid index
-  __shared__ float4 stage_x[kChunk][2 * (kR / 2)];
-  __shared__ float4 stage_yz[kChunk][2 * kR];
-  __shared__ float red[kThreads / 64][20];
-  __shared__ float norm2[20];
+// LDS state of one query's MuPS sweep.  Per staged point: x axis as 4 pairs (i, i+4) laid out for packed math:
+// {q_i, q_i+4, d_i, d_i+4} and {e_i, e_i+4, -, -}; y and z axes as {q, d, d^2-1, -} per grid index
+struct MupsShared {
+  float4 stage_x[kChunk][2 * (kR / 2)];
+  float4 stage_yz[kChunk][2 * kR];
+  float red[kThreads / 64][20];
+  float norm2[20];
+};
 
-  const int b = blockIdx.x;
-  const int t = threadIdx.x;
+// One scale of one query: the 20 statistics of the 512 Gaussians of patch rows 0 .. min(m + 1, P) - 1, written to
+// channels [20 s, 20 s + 20) of the query's 512 output rows.  coord(row, axis) returns the patch coordinate (rows >= m
+// are the reference's zero padding); m = n_eff of this scale.
+template <int DT, class Coord>
+__device__ __forceinline__ void mups_one_scale(MupsShared& sh, Coord coord, int m, int P, int b, int s, void* __restrict__ out,
+                                               int cstride, float sigma, float w, int t) {
   const int k = t & 7, j = (t >> 3) & 7, i0 = t >> 6;
   const int lane = t & 63, wave = t >> 6;
   const int g0 = 64 * i0 + 8 * j + k;
   const int g1 = g0 + 256;
-
-  for (int s = 0; s < S; ++s) {
-    const int m = n_eff[(size_t)b * S + s];
-    const size_t o0 = ((size_t)b * kG + g0) * cstride + 20 * s;
-    const size_t o1 = ((size_t)b * kG + g1) * cstride + 20 * s;
-    if (m <= 0) {   // zero-padded batch tail (test_n_est_w_experts.py:134-140): skip, do not divide by 0
-      float z[20];
+  const size_t o0 = ((size_t)b * kG + g0) * cstride + 20 * s;
+  const size_t o1 = ((size_t)b * kG + g1) * cstride + 20 * s;
+  if (m <= 0) {   // zero-padded batch tail (test_n_est_w_experts.py:134-140): skip, do not divide by 0
+    float z[20];
 #pragma unroll
-      for (int c = 0; c < 20; ++c) z[c] = 0.f;
-      store20<DT>(out, o0, z);
-      store20<DT>(out, o1, z);
-      continue;
-    }
-    // rows 0..m are unmasked: `mask = r > n_eff` (utils/tf_util.py:693), so row m -- normally the
-    // first zero-padding row -- is counted as a point.
-    const int nrows = min(m + 1, P);
-    const bool has_masked = nrows < P;
-    const float* pts = points + ((size_t)b * S + s) * (size_t)P * 3;
+    for (int c = 0; c < 20; ++c) z[c] = 0.f;
+    store20<DT>(out, o0, z);
+    store20<DT>(out, o1, z);
+    return;
+  }
+  // rows 0..m are unmasked: `mask = r > n_eff` (utils/tf_util.py:693), so row m -- normally the
+  // first zero-padding row -- is counted as a point.
+  const int nrows = min(m + 1, P);
+  const bool has_masked = nrows < P;
 
-    Stats acc;
-    acc.init();
+  Stats acc;
+  acc.init();
 
-    for (int c0 = 0; c0 < nrows; c0 += kChunk) {
-      __syncthreads();
-      if (t < 3 * kChunk) {
-        const int axis = t >> 6, nl = t & 63;
-        if (c0 + nl < nrows) {
-          const float x = pts[(size_t)(c0 + nl) * 3 + axis];
-          float d[kR], e[kR], sum = 0.f;
+  for (int c0 = 0; c0 < nrows; c0 += kChunk) {
+    __syncthreads();
+    if (t < 3 * kChunk) {
+      const int axis = t >> 6, nl = t & 63;
+      if (c0 + nl < nrows) {
+        const float x = coord(c0 + nl, axis);
+        float d[kR], e[kR], sum = 0.f;
 #pragma unroll
-          for (int i = 0; i < kR; ++i) {
-            const float mu = -0.875f + 0.25f * (float)i;      // utils/utils.py:81-87 (exact in fp32)
-            d[i] = (x - mu) / sigma;                           // utils/tf_util.py:687
-            e[i] = expf(-0.5f * d[i] * d[i]);
-            sum += e[i];
+        for (int i = 0; i < kR; ++i) {
+          const float mu = -0.875f + 0.25f * (float)i;      // utils/utils.py:81-87 (exact in fp32)
+          d[i] = (x - mu) / sigma;                           // utils/tf_util.py:687
+          e[i] = expf(-0.5f * d[i] * d[i]);
+          sum += e[i];
+        }
+        if (axis == 0) {
+#pragma unroll
+          for (int i = 0; i < kR / 2; ++i) {
+            sh.stage_x[nl][2 * i] = make_float4(e[i] / sum, e[i + 4] / sum, d[i], d[i + 4]);
+            sh.stage_x[nl][2 * i + 1] = make_float4(d[i] * d[i] - 1.0f, d[i + 4] * d[i + 4] - 1.0f, 0.f, 0.f);
           }
-          if (axis == 0) {
+        } else {
 #pragma unroll
-            for (int i = 0; i < kR / 2; ++i) {
-              stage_x[nl][2 * i] = make_float4(e[i] / sum, e[i + 4] / sum, d[i], d[i + 4]);
-              stage_x[nl][2 * i + 1] = make_float4(d[i] * d[i] - 1.0f, d[i + 4] * d[i + 4] - 1.0f, 0.f, 0.f);
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < kR; ++i)
-              stage_yz[nl][(axis - 1) * kR + i] = make_float4(e[i] / sum, d[i], d[i] * d[i] - 1.0f, 0.f);
-          }
+          for (int i = 0; i < kR; ++i)
+            sh.stage_yz[nl][(axis - 1) * kR + i] = make_float4(e[i] / sum, d[i], d[i] * d[i] - 1.0f, 0.f);
         }
       }
-      __syncthreads();
-      const int cnt = min(kChunk, nrows - c0);
-      auto row_terms = [&](int nl, f2* Q, f2 (&d)[3], f2 (&e)[3]) __attribute__((always_inline)) {
-        const float4 XA = stage_x[nl][2 * i0];
-        const float4 XB = stage_x[nl][2 * i0 + 1];
-        const float4 Y = stage_yz[nl][j];
-        const float4 Z = stage_yz[nl][kR + k];
-        asm volatile("" ::"v"(Y.w), "v"(Z.w));   // keep these ds_read_b128: a 12-byte ds_read_b96 costs 8 LDS cycles, not 4
-        const float qyz = Y.x * Z.x;
-        *Q = f2{XA.x, XA.y} * qyz;
-        d[0] = f2{XA.z, XA.w}; d[1] = f2{Y.y, Y.y}; d[2] = f2{Z.y, Z.y};
-        e[0] = f2{XB.x, XB.y}; e[1] = f2{Y.z, Y.z}; e[2] = f2{Z.z, Z.z};
-      };
-      int nl = 0;
-      for (; nl + 1 < cnt; nl += 2) {
-        f2 Qa, Qb, da[3], ea[3], db[3], eb[3];
-        row_terms(nl, &Qa, da, ea);
-        row_terms(nl + 1, &Qb, db, eb);
-        acc.update2(Qa, da, ea, Qb, db, eb);
-      }
-      if (nl < cnt) {
-        f2 Q, d[3], e[3];
-        row_terms(nl, &Q, d, e);
-        acc.update(Q, d, e);
-      }
-    }
-
-    float v0[20], v1[20];
-    const float m_f = (float)m;                    // utils/tf_util.py:722
-    finish(pick(acc, 0), nrows, has_masked, m_f, w, v0);
-    finish(pick(acc, 1), nrows, has_masked, m_f, w, v1);
-
-    // L2 normalisation over the 512 Gaussians, per channel (utils/tf_util.py:738-740)
-    float part[20];
-#pragma unroll
-    for (int c = 0; c < 20; ++c) {
-      float p = v0[c] * v0[c] + v1[c] * v1[c];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) p += __shfl_xor(p, off, 64);
-      part[c] = p;
-    }
-    __syncthreads();   // previous scale's norm2 readers are done
-    if (lane == 0) {
-#pragma unroll
-      for (int c = 0; c < 20; ++c) red[wave][c] = part[c];
     }
     __syncthreads();
-    if (t < 20) norm2[t] = red[0][t] + red[1][t] + red[2][t] + red[3][t];
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 20; ++c) {
-      const float inv = 1.0f / sqrtf(fmaxf(norm2[c], 1e-12f));
-      v0[c] *= inv;
-      v1[c] *= inv;
+    const int cnt = min(kChunk, nrows - c0);
+    auto row_terms = [&](int nl, f2* Q, f2 (&d)[3], f2 (&e)[3]) __attribute__((always_inline)) {
+      const float4 XA = sh.stage_x[nl][2 * i0];
+      const float4 XB = sh.stage_x[nl][2 * i0 + 1];
+      const float4 Y = sh.stage_yz[nl][j];
+      const float4 Z = sh.stage_yz[nl][kR + k];
+      asm volatile("" ::"v"(Y.w), "v"(Z.w));   // keep these ds_read_b128: a 12-byte ds_read_b96 costs 8 LDS cycles, not 4
+      const float qyz = Y.x * Z.x;
+      *Q = f2{XA.x, XA.y} * qyz;
+      d[0] = f2{XA.z, XA.w}; d[1] = f2{Y.y, Y.y}; d[2] = f2{Z.y, Z.y};
+      e[0] = f2{XB.x, XB.y}; e[1] = f2{Y.z, Y.z}; e[2] = f2{Z.z, Z.z};
+    };
+    int nl = 0;
+    for (; nl + 1 < cnt; nl += 2) {
+      f2 Qa, Qb, da[3], ea[3], db[3], eb[3];
+      row_terms(nl, &Qa, da, ea);
+      row_terms(nl + 1, &Qb, db, eb);
+      acc.update2(Qa, da, ea, Qb, db, eb);
     }
-    store20<DT>(out, o0, v0);
-    store20<DT>(out, o1, v1);
+    if (nl < cnt) {
+      f2 Q, d[3], e[3];
+      row_terms(nl, &Q, d, e);
+      acc.update(Q, d, e);
+    }
   }
 
-  // zero the padding channels [20*S, cstride) so downstream GEMMs can read whole rows
+  float v0[20], v1[20];
+  const float m_f = (float)m;                    // utils/tf_util.py:722
+  finish(pick(acc, 0), nrows, has_masked, m_f, w, v0);
+  finish(pick(acc, 1), nrows, has_masked, m_f, w, v1);
+
+  // L2 normalisation over the 512 Gaussians, per channel (utils/tf_util.py:738-740)
+  float part[20];
+#pragma unroll
+  for (int c = 0; c < 20; ++c) {
+    float pp = v0[c] * v0[c] + v1[c] * v1[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pp += __shfl_xor(pp, off, 64);
+    part[c] = pp;
+  }
+  __syncthreads();   // previous scale's norm2 readers are done
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 20; ++c) sh.red[wave][c] = part[c];
+  }
+  __syncthreads();
+  if (t < 20) sh.norm2[t] = sh.red[0][t] + sh.red[1][t] + sh.red[2][t] + sh.red[3][t];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 20; ++c) {
+    const float inv = 1.0f / sqrtf(fmaxf(sh.norm2[c], 1e-12f));
+    v0[c] *= inv;
+    v1[c] *= inv;
+  }
+  store20<DT>(out, o0, v0);
+  store20<DT>(out, o1, v1);
+}
+
+// zero the padding channels [20*S, cstride) of this thread's two output rows so downstream GEMMs can read whole rows
+template <int DT>
+__device__ __forceinline__ void mups_zero_pad(void* __restrict__ out, int b, int S, int cstride, int t) {
   const int pad0 = 20 * S;
   if (pad0 < cstride) {
+    const int k = t & 7, j = (t >> 3) & 7, i0 = t >> 6;
+    const int g0 = 64 * i0 + 8 * j + k, g1 = g0 + 256;
     using E = Elem<DT>;
     typename E::T* o = reinterpret_cast<typename E::T*>(out);
     for (int c = pad0; c < cstride; ++c) {
@@ -278,6 +280,49 @@ __global__ __launch_bounds__(kThreads) void mups_kernel(const float* __restrict_
       o[((size_t)b * kG + g1) * cstride + c] = E::from_f32(0.f);
     }
   }
+}
+
+template <int DT>
+__global__ __launch_bounds__(kThreads) void mups_kernel(const float* __restrict__ points,
+                                                        const int32_t* __restrict__ n_eff, int B,
+                                                        int S, int P, void* __restrict__ out,
+                                                        int cstride, float sigma, float w) {
+  __shared__ MupsShared sh;
+  const int b = blockIdx.x;
+  const int t = threadIdx.x;
+  for (int s = 0; s < S; ++s) {
+    const int m = n_eff[(size_t)b * S + s];
+    const float* pts = points + ((size_t)b * S + s) * (size_t)P * 3;
+    mups_one_scale<DT>(sh, [&](int row, int axis) { return pts[(size_t)row * 3 + axis]; }, m, P, b, s, out, cstride, sigma, w, t);
+  }
+  mups_zero_pad<DT>(out, b, S, cstride, t);
+}
+
+// The product path: ball query + subsample (patches_dev.h) feeding the MuPS sweep directly -- the [B, S*P, 3] patch
+// tensor of the reference's data loader (utils/pcpnet_dataset.py:330-343 -> models/experts_n_est.py:26-35) is never
+// written: the selected neighbour indices stay in LDS and a patch coordinate is formed, with the same IEEE subtraction
+// and division, when the sweep stages it.  Bit-identical to patches_kernel + mups_kernel.
+template <int DT>
+__global__ __launch_bounds__(kThreads) void patches_mups_kernel(const PatchParams p, void* __restrict__ out, int cstride,
+                                                                float sigma, float w) {
+  __shared__ PatchShared psh;
+  __shared__ MupsShared sh;
+  const int q = blockIdx.x;
+  const int t = threadIdx.x;
+  float cf[3];
+  patch_query_setup(p, psh, q, t, cf);
+  for (int s = 0; s < p.S; ++s) {
+    const int n_ball = psh.s_count[s];
+    const int m = patch_select_scale(p, psh, q, t, s, cf);
+    const float rad = p.rad_f[s];
+    mups_one_scale<DT>(sh, [&](int row, int axis) { return row < m ? patch_coord(p, psh.sel[row], axis, cf[axis], rad) : 0.f; },
+                       m, p.P, q, s, out, cstride, sigma, w, t);
+    if (t == 0) {
+      if (p.n_eff_out) p.n_eff_out[(size_t)q * p.S + s] = m;
+      if (p.n_ball_out) p.n_ball_out[(size_t)q * p.S + s] = n_ball;
+    }
+  }
+  mups_zero_pad<DT>(out, q, p.S, cstride, t);
 }
 
 // ---- 3^3 Gaussian grid (27 Gaussians, --num_gaussians 3: the reference's training default, train_n_est_w_experts.py:55)
@@ -417,6 +462,27 @@ int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n
     hipLaunchKernelGGL(mups_kernel<NESTI_BF16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w);
   else
     hipLaunchKernelGGL(mups_kernel<NESTI_F16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_patches_mups(const nesti_config_t* cfg, const float* cloud_dev, int N, const int32_t* query_idx_dev, int M,
+                        const double* r_abs, uint64_t seed, int query_row0, const void* grid_ws_dev, void* out, int out_dtype,
+                        int out_cstride, int32_t* n_eff_out_dev, hipStream_t stream) {
+  if (cfg->grid_n != kR) NESTI_FAIL("launch_patches_mups: the fused kernel serves the 8^3 Gaussian grid");
+  if (cfg->points_per_scale < 1 || 2 * cfg->points_per_scale > kListCap) NESTI_FAIL("launch_patches_mups: points_per_scale must be in [1, 512]");
+  if (out_cstride < 20 * cfg->n_scales || (out_cstride % 4) != 0) NESTI_FAIL("launch_patches_mups: bad channel stride");
+  if (M <= 0) return 0;
+  PatchParams p;
+  patch_params_fill(&p, cfg, cloud_dev, N, query_idx_dev, M, r_abs, seed, query_row0, grid_ws_dev);
+  p.n_eff_out = n_eff_out_dev;
+  const float sigma = (float)sqrt(cfg->variance);
+  const float w = 1.0f / (float)kG;
+  dim3 grid(M), block(kThreads);
+  if (out_dtype == NESTI_F32) hipLaunchKernelGGL(patches_mups_kernel<NESTI_F32>, grid, block, 0, stream, p, out, out_cstride, sigma, w);
+  else if (out_dtype == NESTI_BF16) hipLaunchKernelGGL(patches_mups_kernel<NESTI_BF16>, grid, block, 0, stream, p, out, out_cstride, sigma, w);
+  else if (out_dtype == NESTI_F16) hipLaunchKernelGGL(patches_mups_kernel<NESTI_F16>, grid, block, 0, stream, p, out, out_cstride, sigma, w);
+  else NESTI_FAIL("launch_patches_mups: unknown out_dtype");
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

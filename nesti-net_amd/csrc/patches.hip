@@ -13,37 +13,12 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "patches_dev.h"
 
 namespace nesti {
 namespace {
 
-constexpr int kMaxDim = 128;
-constexpr int kMaxCells = kMaxDim * kMaxDim * kMaxDim;
-constexpr int kThreads = 256;
-constexpr int kListCap = 1024;   // candidates kept for the final rank sort (>= 2P for P = 512)
-
-struct GridHeader {
-  double minv[3];
-  double inv_cell;
-  int dims[3];
-  int ncells;
-};
-
-struct WsLayout {
-  size_t header, bbox, count, start, cursor, sorted, total;
-};
-WsLayout ws_layout(int N) {
-  WsLayout L;
-  size_t o = 0;
-  L.header = o; o += 256;
-  L.bbox = o; o += 256;
-  L.count = o; o += align_up((size_t)(kMaxCells + 1) * 4, 256);
-  L.start = o; o += align_up((size_t)(kMaxCells + 1) * 4, 256);
-  L.cursor = o; o += align_up((size_t)(kMaxCells + 1) * 4, 256);
-  L.sorted = o; o += align_up((size_t)N * 16, 256);
-  L.total = o;
-  return L;
-}
+constexpr int kThreads = kPatchThreads;
 
 __device__ __forceinline__ unsigned f2ord(float f) {
   const unsigned u = __float_as_uint(f);
@@ -104,15 +79,6 @@ __global__ void header_kernel(const unsigned* bb, double cell_min, GridHeader* h
   h->ncells = n;
 }
 
-__device__ __forceinline__ void cell_coords(const GridHeader& h, float x, float y, float z, int* ix, int* iy, int* iz) {
-  *ix = min(h.dims[0] - 1, max(0, (int)floor(((double)x - h.minv[0]) * h.inv_cell)));
-  *iy = min(h.dims[1] - 1, max(0, (int)floor(((double)y - h.minv[1]) * h.inv_cell)));
-  *iz = min(h.dims[2] - 1, max(0, (int)floor(((double)z - h.minv[2]) * h.inv_cell)));
-}
-__device__ __forceinline__ int cell_flat(const GridHeader& h, int ix, int iy, int iz) {
-  return (iz * h.dims[1] + iy) * h.dims[0] + ix;   // x fastest: a row of cells is one contiguous span
-}
-
 __global__ void count_kernel(const float* __restrict__ cloud, int N, const GridHeader* hp, int* count) {
   const GridHeader h = *hp;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
@@ -161,136 +127,25 @@ __global__ void fill_kernel(const float* __restrict__ cloud, int N, const GridHe
   }
 }
 
-// splitmix64 finaliser over (seed, query, scale, point): the documented subsample key
-__device__ __forceinline__ unsigned subsample_hash(unsigned long long seed, unsigned q, unsigned s, unsigned idx) {
-  unsigned long long z = seed ^ ((unsigned long long)q << 34) ^ ((unsigned long long)s << 32) ^ (unsigned long long)idx;
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (unsigned)(z >> 32);
-}
-
-struct PatchParams {
-  const float* cloud;
-  const float4* sorted;
-  const int* start;
-  const GridHeader* header;
-  const int32_t* query_idx;
-  int M, N, S, P, row0;
-  unsigned long long seed;
-  double r2[NESTI_MAX_SCALES];     // r*r, like cKDTree's upper_bound for p = 2
-  float rad_f[NESTI_MAX_SCALES];   // (float)r : torch divides the f32 patch by the scalar in f32
-  float* points_out;
-  int32_t* n_eff_out;
-  int32_t* nbr_out;
-  int32_t* n_ball_out;
-};
-
-__global__ __launch_bounds__(kThreads) void patches_kernel(const PatchParams p) {
-  __shared__ int span_beg[9], span_end[9];
-  __shared__ int s_count[NESTI_MAX_SCALES];
-  __shared__ int s_cnt;
-  __shared__ unsigned long long keys[kListCap];
-  __shared__ int sel[kListCap];
-
+__global__ __launch_bounds__(kPatchThreads) void patches_kernel(const PatchParams p) {
+  __shared__ PatchShared sh;
   const int q = blockIdx.x;
   const int t = threadIdx.x;
-  int qi = p.query_idx ? p.query_idx[q] : p.row0 + q;         // 'full' sampler: patch row == point index
-  qi = min(max(qi, 0), p.N - 1);
-  const GridHeader h = *p.header;
-  const float cxf = p.cloud[(size_t)qi * 3], cyf = p.cloud[(size_t)qi * 3 + 1], czf = p.cloud[(size_t)qi * 3 + 2];
-  const double cx = cxf, cy = cyf, cz = czf;
-
-  if (t < 9) {
-    int ix, iy, iz;
-    cell_coords(h, cxf, cyf, czf, &ix, &iy, &iz);
-    const int zz = iz + t / 3 - 1, yy = iy + t % 3 - 1;
-    int b = 0, e = 0;
-    if (zz >= 0 && zz < h.dims[2] && yy >= 0 && yy < h.dims[1]) {
-      const int x0 = max(ix - 1, 0), x1 = min(ix + 1, h.dims[0] - 1);
-      b = p.start[cell_flat(h, x0, yy, zz)];
-      e = p.start[cell_flat(h, x1, yy, zz) + 1];
-    }
-    span_beg[t] = b;
-    span_end[t] = e;
-  }
-  if (t < NESTI_MAX_SCALES) s_count[t] = 0;
-  __syncthreads();
-
-  // ---- pass A: ball sizes ------------------------------------------------------------------
-  int local[NESTI_MAX_SCALES] = {0, 0, 0, 0};
-  for (int sp = 0; sp < 9; ++sp) {
-    for (int i = span_beg[sp] + t; i < span_end[sp]; i += kThreads) {
-      const float4 c = p.sorted[i];
-      const double dx = (double)c.x - cx, dy = (double)c.y - cy, dz = (double)c.z - cz;
-      double d2 = __dmul_rn(dx, dx);
-      d2 = __dadd_rn(d2, __dmul_rn(dy, dy));
-      d2 = __dadd_rn(d2, __dmul_rn(dz, dz));
-#pragma unroll
-      for (int s = 0; s < NESTI_MAX_SCALES; ++s)
-        if (s < p.S && d2 <= p.r2[s]) ++local[s];
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < NESTI_MAX_SCALES; ++s)
-    if (s < p.S && local[s]) atomicAdd(&s_count[s], local[s]);
-  __syncthreads();
-
+  float cf[3];
+  patch_query_setup(p, sh, q, t, cf);
   for (int s = 0; s < p.S; ++s) {
-    const int n_ball = s_count[s];
-    const int n_eff = min(n_ball, p.P);   // utils/pcpnet_dataset.py:310
-    // ---- pass B: collect the hits whose key is <= T; T is bisected until P <= kept <= cap --
-    unsigned lo = 0u, hi = 0xffffffffu, T = 0xffffffffu;
-    if (n_ball > p.P) T = (unsigned)fmin(4294967295.0, 4294967296.0 * 1.25 * (double)p.P / (double)n_ball);
-    int kept = 0;
-    for (int iter = 0; iter < 40; ++iter) {
-      __syncthreads();
-      if (t == 0) s_cnt = 0;
-      __syncthreads();
-      for (int sp = 0; sp < 9; ++sp) {
-        for (int i = span_beg[sp] + t; i < span_end[sp]; i += kThreads) {
-          const float4 c = p.sorted[i];
-          const double dx = (double)c.x - cx, dy = (double)c.y - cy, dz = (double)c.z - cz;
-          double d2 = __dmul_rn(dx, dx);
-          d2 = __dadd_rn(d2, __dmul_rn(dy, dy));
-          d2 = __dadd_rn(d2, __dmul_rn(dz, dz));
-          if (d2 <= p.r2[s]) {
-            const unsigned idx = (unsigned)__float_as_int(c.w);
-            const unsigned hsh = subsample_hash(p.seed, (unsigned)(p.row0 + q), (unsigned)s, idx);
-            if (hsh <= T) {
-              const int pos = atomicAdd(&s_cnt, 1);
-              if (pos < kListCap) keys[pos] = ((unsigned long long)hsh << 32) | idx;
-            }
-          }
-        }
-      }
-      __syncthreads();
-      kept = s_cnt;
-      if (kept >= n_eff && kept <= kListCap) break;
-      if (kept < n_eff) lo = T + 1u; else hi = T - 1u;
-      T = lo + (hi - lo) / 2u;
-    }
-    kept = min(kept, kListCap);
-    // ---- rank sort: position = number of smaller keys; keep the first n_eff -----------------
-    for (int e = t; e < kept; e += kThreads) {
-      const unsigned long long my = keys[e];
-      int rank = 0;
-      for (int j = 0; j < kept; ++j) rank += (keys[j] < my) ? 1 : 0;
-      if (rank < n_eff) sel[rank] = (int)(unsigned)(my & 0xffffffffull);
-    }
-    __syncthreads();
+    const int n_ball = sh.s_count[s];
+    const int n_eff = patch_select_scale(p, sh, q, t, s, cf);
     const float rad = p.rad_f[s];
-    for (int r = t; r < p.P; r += kThreads) {
+    for (int r = t; r < p.P; r += kPatchThreads) {
       const size_t row = ((size_t)q * p.S + s) * p.P + r;
       float ox = 0.f, oy = 0.f, oz = 0.f;
       int idx = -1;
       if (r < n_eff) {
-        idx = sel[r];
-        // (pts[idx] - pts[center]) / rad in f32  (utils/pcpnet_dataset.py:330-343)
-        ox = __fdiv_rn(__fsub_rn(p.cloud[(size_t)idx * 3], cxf), rad);
-        oy = __fdiv_rn(__fsub_rn(p.cloud[(size_t)idx * 3 + 1], cyf), rad);
-        oz = __fdiv_rn(__fsub_rn(p.cloud[(size_t)idx * 3 + 2], czf), rad);
+        idx = sh.sel[r];
+        ox = patch_coord(p, idx, 0, cf[0], rad);
+        oy = patch_coord(p, idx, 1, cf[1], rad);
+        oz = patch_coord(p, idx, 2, cf[2], rad);
       }
       if (p.points_out) {
         p.points_out[row * 3] = ox;
@@ -313,14 +168,14 @@ using namespace nesti;
 
 extern "C" {
 
-size_t nesti_patches_workspace_bytes(int N) { return N > 0 ? ws_layout(N).total : 0; }
+size_t nesti_patches_workspace_bytes(int N) { return N > 0 ? patch_ws_layout(N).total : 0; }
 
 int nesti_patches_grid(const nesti_config_t* cfg, const float* cloud_dev, int N, const double* r_abs,
                        void* grid_ws_dev, size_t grid_ws_bytes, void* stream) {
   if (!cfg || !cloud_dev || !r_abs || !grid_ws_dev) NESTI_FAIL("nesti_patches_grid: null argument");
   if (N <= 0) NESTI_FAIL("nesti_patches_grid: empty cloud");
   if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("nesti_patches_grid: bad n_scales");
-  const WsLayout L = ws_layout(N);
+  const WsLayout L = patch_ws_layout(N);
   if (grid_ws_bytes < L.total) NESTI_FAIL("nesti_patches_grid: grid workspace too small");
   hipStream_t st = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)grid_ws_dev;
@@ -356,7 +211,7 @@ int nesti_patches_query(const nesti_config_t* cfg, const float* cloud_dev, int N
   if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("nesti_patches_query: bad n_scales");
   if (cfg->points_per_scale < 1 || 2 * cfg->points_per_scale > kListCap)
     NESTI_FAIL("nesti_patches_query: points_per_scale must be in [1, 512]");
-  const WsLayout L = ws_layout(N);
+  const WsLayout L = patch_ws_layout(N);
   if (grid_ws_bytes < L.total) NESTI_FAIL("nesti_patches_query: grid workspace too small");
   if (M <= 0) return 0;
   // 'full' sampler (query_idx NULL): patch row == point index, so the row range must lie inside the cloud.  With a
@@ -365,20 +220,10 @@ int nesti_patches_query(const nesti_config_t* cfg, const float* cloud_dev, int N
   if (query_row0 < 0) NESTI_FAIL("nesti_patches_query: query_row0 must be >= 0");
   if (!query_idx_dev && (long long)query_row0 + M > (long long)N)
     NESTI_FAIL("nesti_patches_query: query rows [query_row0, query_row0 + M) exceed the cloud (N points)");
-  const unsigned char* ws = (const unsigned char*)grid_ws_dev;
-  PatchParams p;
-  memset(&p, 0, sizeof(p));
-  p.cloud = cloud_dev;
-  p.sorted = (const float4*)(ws + L.sorted);
-  p.start = (const int*)(ws + L.start);
-  p.header = (const GridHeader*)(ws + L.header);
-  p.query_idx = query_idx_dev;
-  p.M = M; p.N = N; p.S = cfg->n_scales; p.P = cfg->points_per_scale; p.seed = seed; p.row0 = query_row0;
-  for (int s = 0; s < cfg->n_scales; ++s) {
+  for (int s = 0; s < cfg->n_scales; ++s)
     if (!(r_abs[s] > 0.0)) NESTI_FAIL("nesti_patches_query: radii must be positive");
-    p.r2[s] = r_abs[s] * r_abs[s];
-    p.rad_f[s] = (float)r_abs[s];
-  }
+  PatchParams p;
+  patch_params_fill(&p, cfg, cloud_dev, N, query_idx_dev, M, r_abs, seed, query_row0, grid_ws_dev);
   p.points_out = points_out_dev; p.n_eff_out = n_eff_out_dev; p.nbr_out = nbr_idx_out_dev; p.n_ball_out = n_ball_out_dev;
   const int tok = prof_begin(NESTI_PROF_PATCHES, (hipStream_t)stream);
   hipLaunchKernelGGL(patches_kernel, dim3(M), dim3(kThreads), 0, (hipStream_t)stream, p);

@@ -42,6 +42,7 @@ def _fixture_config(g):
 def _oracle_moe(mups, W, cfg, chunk=64):
     """oracle.net_ref.moe_forward in chunks (bounds host memory); fp64."""
     from oracle import net_ref
+    torch.set_num_threads(min(32, os.cpu_count() or 1))      # torch-CPU conv3d regresses well before 256 threads
     outs = [net_ref.moe_forward(mups[i:i + chunk], W, expert_dict=cfg.expert_dict, dtype=torch.float64, top1_only=True)
             for i in range(0, len(mups), chunk)]
     return {k: torch.cat([o[k] for o in outs]).numpy() for k in ("probs", "expert", "normals")}
@@ -164,4 +165,4 @@ def test_fp32_mode_is_batching_invariant_and_self_consistent(big_case, gpu_devic
     for x, y in zip(out, ref):
         assert np.array_equal(x, y[:3000])
     rep = parity.compare(out, [r[:3000] for r in ref])
-    assert rep["meets_north_star"] and rep["argmax_flips"] == 0 and rep["one_minus_cos"]["max"] == 0.0
+    assert rep["meets_north_star"] and rep["argmax_flips"] == 0 and rep["one_minus_cos"]["max"] < 1e-12

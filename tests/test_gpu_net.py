@@ -13,7 +13,7 @@ from conftest import golden_patch_files, load_golden_patches
 pytestmark = pytest.mark.gpu
 
 COS_TOL_F32 = 1e-5
-PROB_TOL_F32 = 2e-5
+PROB_TOL_F32 = 1e-4     # fp32 MFMA vs fp64 oracle on softmax outputs of O(1)-spread logits
 
 
 def _cos(a, b):

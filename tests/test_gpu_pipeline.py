@@ -285,3 +285,45 @@ def test_config4_stream_of_32_clouds_graph_matches_eager(gpu_device):
     a, b = n_g[:len(fq)][agree].astype(np.float64), ref["normals"].numpy()[agree]
     cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
     assert np.all(1 - cos < 1e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_fused_entry_matches_the_two_call_path(gpu_device, dtype):
+    """nesti_estimate_normals (cloud -> patches_mups_kernel -> gate -> routed experts; the patch tensors are never
+    written) against the parity entry points it fuses (nesti_patches_query -> nesti_forward, which materialise the
+    reference's [B, S*P, 3] placeholder): bit-identical outputs, on a cloud whose small-radius balls hold only a
+    handful of points (striped density + the strongest PCPNet noise), with sparse queries and ragged batches."""
+    import ctypes
+    from nesti_net_amd import _lib, synth, weights
+    from nesti_net_amd.calibrate import calibrate_gate
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from nesti_net_amd.pipeline import NormalEstimator
+    from nesti_net_amd.provider import CloudPatches
+    cfg = NestiConfig()
+    pts = synth.make_cloud("sphere", n=40000, seed=1238, noise=0.012, density="striped")[0]
+    q = np.arange(5, 40000, 61)
+    cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
+    p_all, n_all = cp.build(0, len(q))
+    assert int(n_all[:, 0].min()) <= 3                      # tiny balls are in the set
+    W = calibrate_gate(cfg, weights.synthetic_weights(cfg), p_all, n_all, device=gpu_device)
+    net = NestiNet(cfg, W, dtype=dtype, device=gpu_device, max_batch=len(q))
+    ref = [t.cpu().numpy() for t in net(p_all, n_all)]
+    est = NormalEstimator(cfg, W, dtype=dtype, device=gpu_device, batch=250)       # 656 queries: 250 + 250 + 156
+    assert est._fused
+    got = est.estimate(pts, pidx=q)
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)
+    assert len(np.unique(ref[1])) >= 5
+    # misuse is reported, not executed
+    lib = _lib.load()
+    cloud = est.prepare(pts)
+    out = torch.empty((10, 3), dtype=torch.float32, device=gpu_device)
+    args = lambda row0, m, ws_bytes: (est.net._handle, _lib.ptr(cloud.cloud), cloud.n_points, None, m, cloud._r, ctypes.c_uint64(1),
+                                      row0, 250, 0, _lib.ptr(cloud._ws), cloud._ws.numel(), _lib.ptr(est._arena), ws_bytes,
+                                      _lib.ptr(out), None, None, None)
+    assert lib.nesti_estimate_normals(*args(39995, 10, est._arena.numel())) != 0 and b"exceed the cloud" in lib.nesti_last_error()
+    assert lib.nesti_estimate_normals(*args(0, 10, 1024)) != 0 and b"workspace too small" in lib.nesti_last_error()
+    assert lib.nesti_estimate_normals(*args(0, 10, est._arena.numel())) == 0
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all())
