@@ -196,83 +196,24 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   };
 
   if constexpr (KPIPE) {
-    // ---- one tap (1x1x1 / FC): a 4-deep ring of HALF chunks (64 B per row: 2 K-steps) ---------------------------
-    // These layers move 80 KiB of operands per 32 MFMAs of a wave and run at the LDS-DMA latency, not at the matrix
-    // pipe (pipe busy 20-35 %): with two whole-chunk buffers only one chunk is in flight while one multiplies.  Stages
-    // of half a chunk (A 32 KiB + B TN x 64 B) leave room for four, so three stages -- 1.5 chunks -- are in flight
-    // behind the one being multiplied, waited for with a COUNTED vmcnt (every wave issues exactly 5 DMA pieces per
-    // stage) instead of a drain, one barrier per stage.  LDS rows are 64 B, 16-B slot XOR (row >> 2) & 3.
-    constexpr int kStA = kTileM * 64;                    // 32 KiB
-    constexpr int kStB = TN * 64;
-    constexpr int kStage = kStA + kStB;
-    const int NH = 2 * p.n_chunks;
-    // A: wave w, piece j covers rows (4 w + j) * 16 .. + 16; lane -> (row, slot')
-    long long a4_off[4];
+    // ---- one tap: software pipeline over input-channel chunks --------------------------------
+    int a_addr[2], a_sw[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row_l = (wave * 4 + j) * 16 + (lane >> 2);
-      const int kslot = (lane & 3) ^ ((row_l >> 2) & 3);
-      const long long gr = r0 + row_l;
-      if (gr < total_rows) {
-        long long pt = gr >> log2V;
-        const long long vox = gr & (V - 1);
-        if (p.point_index) pt = p.point_index[pt];
-        a4_off[j] = (((pt << log2V) + vox) * p.in_cstride + p.in_coff) * kEsz + kslot * 16;
-      } else {
-        a4_off[j] = -1;
+    for (int mi = 0; mi < 2; ++mi) { a_addr[mi] = rrow[mi] * kRowBytes; a_sw[mi] = swz_key(rrow[mi]); }
+    stage_a(0, 0);
+    stage_b(0, 0, 0);
+    wait_vm0();
+    __syncthreads();
+    for (int c = 0; c < p.n_chunks; ++c) {
+      const int cur = c & 1;
+      if (c + 1 < p.n_chunks) {
+        stage_a(c + 1, cur ^ 1);
+        stage_b(c + 1, 0, cur ^ 1);
       }
+      compute(true, true, As + cur * kABytes, Bs + cur * kBTile, a_addr, a_sw);
+      wait_vm0();
+      __syncthreads();
     }
-    // B: piece q covers tile rows 16 q .. + 16 (TN / 16 pieces; with TN = 64 waves 4-7 repeat pieces 0-3 so that every
-    // wave issues the same number of DMAs).  The packed tile has 128-B rows, slot XOR (row >> 1) & 7 (model.hip).
-    const int b_piece = wave % (TN / 16);
-    const int b_rowl = b_piece * 16 + (lane >> 2);
-    const int b_kslot = (lane & 3) ^ ((b_rowl >> 2) & 3);
-    auto stage = [&](int h) __attribute__((always_inline)) {
-      const int c = h >> 1, half = h & 1, slot = h & 3;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (a4_off[j] >= 0)
-          glds16(in_b + a4_off[j] + (long long)c * kRowBytes + half * 64, lds0 + slot * kStage + (wave * 4 + j) * 1024);
-        else
-          glds16(in_b, lds0 + slot * kStage + (wave * 4 + j) * 1024);   // rows beyond the batch: any valid address (never stored)
-      }
-      const unsigned char* src = w_tile + (size_t)c * kBTile + b_rowl * kRowBytes + (((half * 4 + b_kslot) ^ ((b_rowl >> 1) & 7)) << 4);
-      glds16(src, lds0 + slot * kStage + kStA + b_piece * 1024);
-    };
-    int a_addr[2];
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) a_addr[mi] = rrow[mi] * 64;
-    const int a_key0 = (rrow[0] >> 2) & 3, a_key1 = (rrow[1] >> 2) & 3;
-    const int b_row64 = (lane & 31) * 64, b_key = ((lane & 31) >> 2) & 3;
-    for (int h = 0; h < 3 && h < NH; ++h) stage(h);
-    for (int h = 0; h < NH; ++h) {
-      const int ahead = min(2, NH - 1 - h);              // stages issued after stage h that may stay in flight
-      if (ahead == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                                   // stage h landed for everyone; everyone is done with stage h - 1
-      if (h + 3 < NH) stage(h + 3);
-      const unsigned char* Acur = smem + (h & 3) * kStage;
-      const unsigned char* Bcur = Acur + kStA;
-      uint4 af[2][2], bf[2][NI];
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int slot = kk * 2 + khalf;
-        af[kk][0] = *reinterpret_cast<const uint4*>(Acur + a_addr[0] + ((slot ^ a_key0) << 4));
-        af[kk][1] = *reinterpret_cast<const uint4*>(Acur + a_addr[1] + ((slot ^ a_key1) << 4));
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          bf[kk][ni] = *reinterpret_cast<const uint4*>(Bcur + ni * 32 * 64 + b_row64 + ((slot ^ b_key) << 4));
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[0][ni], af[kk][0], bf[kk][ni]);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[1][ni], af[kk][1], bf[kk][ni]);
-      }
-    }
-    __syncthreads();                                     // nobody still reads the ring: the LDS becomes the epilogue tile
   } else {
     // ---- k^3 taps: A chunk resident, weight tiles double-buffered -----------------------------
     if (tid < 32) reinterpret_cast<uint32_t*>(smem + kZeroOff)[tid] = 0u;
@@ -570,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 template <int TN, bool KPIPE>
 constexpr size_t lds_bytes() {
   constexpr size_t kPoolTile = (size_t)kTileM * kPoolStride + 16;         // fp32 pooling tile of the epilogues
-  constexpr size_t loop = KPIPE ? (size_t)4 * (kTileM * 64 + TN * 64)               // 4 half-chunk stages: 160 KiB at TN = 128
+  constexpr size_t loop = KPIPE ? (size_t)2 * kABytes + 2 * TN * kRowBytes         // 160 KiB at TN = 128
                                 : (size_t)kABytes + 4 * TN * kRowBytes + kRowBytes; // 4 weight slots + zero row
   return loop > kPoolTile ? loop : kPoolTile;
 }
