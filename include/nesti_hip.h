@@ -193,10 +193,9 @@ int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N
                            void* stream);
 
 /* ---- text I/O of the file seam (host only) ------------------------------------------------
- * np.loadtxt(<shape>.xyz).astype('float32') (utils/pcpnet_dataset.py:250): call with out == NULL for
- * the shape, then with a [n_rows, take_cols] float32 buffer.  Empty lines and '#' comments are skipped. */
-int nesti_read_text_matrix(const char* path, float* out, int64_t cap_rows, int take_cols,
-                           int64_t* n_rows, int* n_cols);
+ * Reading stays np.loadtxt (utils/pcpnet_dataset.py:250): numpy 2's parser is faster than a strtod loop, and the
+ * .npy cache the reference writes next to the file makes it a one-off.  The writers are native: np.savetxt's
+ * '%.18e' formatting dominates the wall time of a shape once the compute takes a second. */
 /* np.savetxt(path, a) with the default '%.18e' format (test_n_est_w_experts.py:182-183, 187-188). */
 int nesti_write_text_f32(const char* path, const float* data, int64_t rows, int cols);
 /* np.savetxt(path, a.astype(int), fmt='%i') (test_n_est_w_experts.py:185-186). */

@@ -51,8 +51,6 @@ SIGNATURES = {
     "nesti_estimate_workspace_bytes": (_sz, [_vp, _i]),
     "nesti_estimate_normals": (_i, [_vp, _vp, _i, _vp, _i, ctypes.POINTER(ctypes.c_double), _u64, _i, _i, _i, _vp, _sz,
                                     _vp, _sz, _vp, _vp, _vp, _vp]),
-    "nesti_read_text_matrix": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64, _i, ctypes.POINTER(ctypes.c_int64),
-                                    ctypes.POINTER(_i)]),
     "nesti_write_text_f32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64, _i]),
     "nesti_write_text_i32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64]),
     "nesti_profile_enable": (_i, [_i]),

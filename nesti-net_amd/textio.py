@@ -1,26 +1,9 @@
-"""Fast text I/O of the file seam (native code in ``csrc/textio.cpp``), byte-compatible with the
-numpy calls the reference uses: ``np.loadtxt(...).astype('float32')`` for ``<shape>.xyz``
-(``utils/pcpnet_dataset.py:250``) and ``np.savetxt`` for ``.normals`` / ``.experts`` /
-``.experts_probs`` (``test_n_est_w_experts.py:182-188``)."""
-import ctypes
-
+"""Fast text output of the file seam (native code in ``csrc/textio.cpp``), byte-identical to the ``np.savetxt`` calls
+the reference uses for ``.normals`` / ``.experts`` / ``.experts_probs`` (``test_n_est_w_experts.py:182-188``).  Reading
+``<shape>.xyz`` stays ``np.loadtxt`` + the ``.npy`` cache (``provider.load_xyz``, ``utils/pcpnet_dataset.py:249-251``)."""
 import numpy as np
 
 from . import _lib
-
-
-def read_matrix(path, take_cols=None):
-    """Whitespace-separated numeric text -> float32 [rows, take_cols or all columns]."""
-    lib = _lib.load()
-    n, c = ctypes.c_int64(0), ctypes.c_int(0)
-    bpath = path.encode()
-    _lib.check(lib.nesti_read_text_matrix(bpath, None, 0, 0, ctypes.byref(n), ctypes.byref(c)), "nesti_read_text_matrix")
-    cols = c.value if take_cols is None else int(take_cols)
-    out = np.empty((n.value, cols), np.float32)
-    if n.value:
-        _lib.check(lib.nesti_read_text_matrix(bpath, _lib.ptr(out), n.value, cols, ctypes.byref(n), ctypes.byref(c)),
-                   "nesti_read_text_matrix")
-    return out
 
 
 def write_f32(path, a):
