@@ -65,3 +65,23 @@ def test_bench_two_ranks_debug_single_device(gpu_device):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["points_per_cloud"] == 6000 and sum(d["config"]["routing_histogram"]) == 6000
     assert d["parity"]["queries"] == 3000 and d["parity"]["one_minus_cos"]["p50"] <= 2e-5
+
+
+def test_second_device_in_one_process(gpu_device):
+    """The conv kernels opt in to > 64 KiB of dynamic LDS per DEVICE (hipFuncSetAttribute); a model built on a second
+    device after the first must get its own opt-in.  Needs two GPUs; skipped on the 1-GPU pool."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two devices")
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import synth, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.pipeline import NormalEstimator
+    cfg = NestiConfig()
+    W = weights.synthetic_weights(cfg)
+    pts = synth.make_cloud("sphere", n=4000, seed=3)[0]
+    q = np.arange(0, 4000, 9)
+    a = NormalEstimator(cfg, W, dtype="f16", device="cuda:0", batch=256).estimate(pts, pidx=q)
+    b = NormalEstimator(cfg, W, dtype="f16", device="cuda:1", batch=256).estimate(pts, pidx=q)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
