@@ -166,7 +166,7 @@ def mups_only(args, cfg, dev):
     return 0
 
 
-def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, use_pg, timing):
+def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, use_pg, timing, want_shard0=True):
     """W warm-up steps, then exactly ``steps`` timed steps between barrier + synchronize pairs; max over ranks.
     Returns the elapsed seconds, the kernel-time categories (rank 0), the last cloud's gathered results, this rank's
     results for its shard of cloud 0 (for the parity leg) and the model's MAC counts."""
@@ -212,8 +212,9 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     res = {"elapsed": elapsed, "prof_ms": list(prof_ms), "prof_n": list(prof_n), "batch": est.batch,
            "out": [t.cpu().numpy() for t in out]}
     if rank == 0:
-        lo, hi = ndist.shard_range(clouds[0].patch_count, 0, world)
-        res["shard0"] = [t.cpu().numpy() for t in est.run(clouds[0], lo, hi - lo)]     # outside the timed region
+        if want_shard0:
+            lo, hi = ndist.shard_range(clouds[0].patch_count, 0, world)
+            res["shard0"] = [t.cpu().numpy() for t in est.run(clouds[0], lo, hi - lo)]     # outside the timed region
         h = est.net._handle
         nom, use, iss = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         macs = {}
@@ -307,12 +308,13 @@ def main():
         W = calibrate_gate(cfg, W, sp, sn, device=dev)
         del cp, sp, sn
     timing = (rank == 0) and not args.no_kernel_timing
-    main_run = timed_run(args, cfg, W, clouds_np, args.dtype, args.steps, args.warmup, dev, world, rank, use_pg, timing)
+    main_run = timed_run(args, cfg, W, clouds_np, args.dtype, args.steps, args.warmup, dev, world, rank, use_pg, timing,
+                         want_shard0=not args.no_parity and args.dtype != "f32")
     second = None
     if not args.no_secondary and args.dtype == "f16" and not args.stream_clouds:
         # the same workload in bf16 (the dtype BASELINE config 2 names), 3 timed steps: reported beside the headline with
         # its own parity distribution -- it is faster but does not meet the 1e-5 cosine tolerance
-        second = timed_run(args, cfg, W, clouds_np, "bf16", 3, 1, dev, world, rank, use_pg, timing)
+        second = timed_run(args, cfg, W, clouds_np, "bf16", 3, 1, dev, world, rank, use_pg, timing, want_shard0=not args.no_parity)
 
     if rank == 0:
         elapsed = main_run["elapsed"]

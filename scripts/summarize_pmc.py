@@ -42,7 +42,7 @@ def load(c):
 f, nf = load("FETCH_SIZE")
 w, nw = load("WRITE_SIZE")
 res = {"queries": queries, "dtype": dtype, "batch": batch, "calibrated_gate": True,
-       "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity --no-secondary under rocprofv3 --pmc",
+       "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity --no-secondary under rocprofv3 --pmc (one pass over the cloud)",
        "note": "FETCH_SIZE doubled per the gfx950 correction; units KiB -> bytes; 'conv' = conv8_kernel + conv_igemm_kernel", "kernels": {}}
 for k in sorted(set(f) | set(w)):
     rd, wr = 2.0 * f[k] * 1024, w[k] * 1024
