@@ -251,9 +251,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=100000, help="points per cloud (= queries per rank per step)")
-    ap.add_argument("--batch", type=int, default=50000,
-                    help="queries per library call (workspace ~2.6 MB per query in f16: 130 GB of the 288 GB at 50 000; "
-                         "+1.5 %% over 25 000 -- the per-expert launches fill the chip in fewer, fuller rounds)")
+    ap.add_argument("--batch", type=int, default=100000,
+                    help="queries per library call (workspace ~1.7 MB per query in f16: a whole 100k-point cloud is one batch; "
+                         "+1.5 %% from 25 000 to 50 000 and +1.2 %% more to 100 000 -- the per-expert launches fill the chip in "
+                         "fewer, fuller rounds)")
     ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "f32"],
                     help="f16 (default) meets the north star's 1e-5 cosine tolerance against the fp32 mode; bf16 does not")
     ap.add_argument("--no-cpu-baseline", action="store_true")

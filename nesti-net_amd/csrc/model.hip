@@ -576,11 +576,66 @@ size_t buf_bytes(const BufSpec& b, int NB, int dtype) {
   const size_t e = b.f32 ? 4 : dtype_size(dtype);
   return align_up(((size_t)NB << (3 * b.log2S)) * b.C * e, 256);
 }
-size_t tower_bytes(const Tower& T, int NB, int dtype) {
-  size_t s = 0;
-  for (size_t i = 1; i < T.bufs.size(); ++i) s += buf_bytes(T.bufs[i], NB, dtype);
-  return s;
+// Workspace placement of a tower's buffers: a buffer lives from the first launch that writes it to the last launch that
+// reads it (the tower's output until the end); buffers whose lifetimes do not overlap share memory (first fit), which
+// brings the gating tower from 2.5 to 1.6 MB per query in 16-bit and lets one library batch cover a 100k-point cloud.
+struct Placement {
+  std::vector<size_t> off;   // per buffer (index 0 = the external MuPS tensor: unused)
+  size_t total = 0;
+};
+Placement place_tower(const Tower& T, int NB, int dtype) {
+  const int n = (int)T.bufs.size(), n_ops = (int)T.ops.size();
+  std::vector<int> first(n, 1 << 30), last(n, -1);
+  for (int k = 0; k < n_ops; ++k) {
+    const Op& op = T.ops[k];
+    for (int b : {op.out_buf, op.mp_buf})
+      if (b >= 1) { first[b] = std::min(first[b], k); last[b] = std::max(last[b], k); }
+    if (op.in_buf >= 1) last[op.in_buf] = std::max(last[op.in_buf], k);
+  }
+  if (T.out_buf >= 1) last[T.out_buf] = n_ops;
+  std::vector<int> order;
+  for (int i = 1; i < n; ++i) if (last[i] >= 0) order.push_back(i);
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return first[a] != first[b] ? first[a] < first[b] : a < b; });
+  struct Block { size_t off, size; int until; };
+  std::vector<Block> live, freeb;
+  Placement P;
+  P.off.assign(n, 0);
+  for (int i : order) {
+    // release what is no longer read, coalescing neighbours
+    for (size_t j = 0; j < live.size();) {
+      if (live[j].until < first[i]) { freeb.push_back(live[j]); live.erase(live.begin() + j); } else ++j;
+    }
+    std::sort(freeb.begin(), freeb.end(), [](const Block& a, const Block& b) { return a.off < b.off; });
+    for (size_t j = 0; j + 1 < freeb.size();) {
+      if (freeb[j].off + freeb[j].size == freeb[j + 1].off) { freeb[j].size += freeb[j + 1].size; freeb.erase(freeb.begin() + j + 1); } else ++j;
+    }
+    const size_t need = buf_bytes(T.bufs[i], NB, dtype);
+    size_t at = (size_t)-1;
+    for (size_t j = 0; j < freeb.size(); ++j) {
+      if (freeb[j].size >= need) {
+        at = freeb[j].off;
+        freeb[j].off += need; freeb[j].size -= need;
+        if (freeb[j].size == 0) freeb.erase(freeb.begin() + j);
+        break;
+      }
+    }
+    if (at == (size_t)-1) {
+      // grow at the top; a free block that ends at the top is extended instead of wasted
+      if (!freeb.empty() && freeb.back().off + freeb.back().size == P.total) {
+        at = freeb.back().off;
+        P.total = at + need;
+        freeb.pop_back();
+      } else {
+        at = P.total;
+        P.total += need;
+      }
+    }
+    P.off[i] = at;
+    live.push_back({at, need, last[i]});
+  }
+  return P;
 }
+size_t tower_bytes(const Tower& T, int NB, int dtype) { return place_tower(T, NB, dtype).total; }
 
 // Which k^3 layers use the Latin-square tile layout (kernels.h: ConvParams::remap): those where a 32-row tile can
 // fall entirely on padding -- 5^3 taps at 8^3 (|d| = 2 clears a y/z pair) and every multi-tap layer at 4^3.  3^3 at
@@ -604,12 +659,9 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
   const int dtype = rc.m->dtype;
   std::vector<unsigned char*> ptr(T.bufs.size(), nullptr);
   ptr[0] = (unsigned char*)X0;
-  size_t off = 0;
-  for (size_t i = 1; i < T.bufs.size(); ++i) {
-    ptr[i] = ws + off;
-    off += buf_bytes(T.bufs[i], rc.NB, dtype);
-  }
-  if (off > ws_bytes) NESTI_FAIL("workspace too small for this batch");
+  const Placement P = place_tower(T, rc.NB, dtype);
+  for (size_t i = 1; i < T.bufs.size(); ++i) ptr[i] = ws + P.off[i];
+  if (P.total > ws_bytes) NESTI_FAIL("workspace too small for this batch");
   for (const Op& op : T.ops) {
     const bool ext_in = op.in_buf < 1;
     if (op.kind == Op::CONV) {

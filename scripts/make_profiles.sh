@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the judged profile artefacts on the GPU box into gpurun_out/profiles/ (copy them into profiles/r02_* afterwards):
-#   bench_n1.json               python3 bench.py (default command: f16, calibrated gate, batch 50 000)
+#   bench_n1.json               python3 bench.py (default command: f16, calibrated gate, batch 100 000)
 #   bench_under_rocprof.json    the same command under rocprofv3 --kernel-trace --stats
 #   bench_kernel_stats.csv      its per-kernel summary (average duration must agree with roofline.avg_launch_ms)
 #   pmc_traffic.json            HBM bytes from separate --pmc FETCH_SIZE / WRITE_SIZE passes of ONE step of the same
@@ -16,5 +16,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc/pmc_$c && rocprofv3 --pmc $c --output-format csv -d /tmp/pmc/pmc_$c -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity --no-secondary > /tmp/pmc_$c.log 2>&1
   f=$(find /tmp/pmc/pmc_$c -name "*counter_collection.csv" | head -1); mkdir -p /tmp/pmc/pmc_$c; cp $f /tmp/pmc/pmc_$c/p_counter_collection.csv
 done
-python3 $R/scripts/summarize_pmc.py /tmp/pmc 100000 $O/pmc_traffic.json f16 50000
+python3 $R/scripts/summarize_pmc.py /tmp/pmc 100000 $O/pmc_traffic.json f16 100000
 head -c 600 $O/bench_n1.json; echo; head -8 $O/bench_kernel_stats.csv
