@@ -161,6 +161,9 @@ def mups_only(args, cfg, dev):
         "roofline": {"bound": "valu", "kernel": "mups_kernel", "achieved": valu_ops / mups_s / 1e12, "peak": 78.6,
                      "unit": "Tlane-op/s (fp32 VALU issue: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz)",
                      "frac": valu_ops / mups_s / 1e12 / 78.6,
+                     # SURVEY.md 8(d)'s own formula: 27 flop x 512 Gaussians x patch rows per query, against the 157.3 TFLOP/s
+                     # fp32 vector peak (which counts an FMA as two flops; the max / min / compare half of this mix cannot fuse)
+                     "survey_flops_frac_of_157TFLOPs": 27.0 * 512 * rows_per_q * q / mups_s / 1e12 / 157.3,
                      "hbm_GBps": q * (122880 + 18432 + 12) / mups_s / 1e9, "hbm_frac_of_8TBps": q * 141324 / mups_s / 8e12,
                      "kernel_ms_per_step": {"mups": ms[1] / args.steps, "patches": ms[3] / args.steps}}}))
     return 0
