@@ -174,17 +174,16 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     Returns the elapsed seconds, the kernel-time categories (rank 0), the last cloud's gathered results, this rank's
     results for its shard of cloud 0 (for the parity leg) and the model's MAC counts."""
     lib = _lib.load()
-    max_shard = max(ndist.max_shard(len(p), world) for p, _ in clouds_np)      # rows of one cloud on one rank
-    est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=min(args.batch, max_shard), use_graph=args.graph,
+    rank_rows = sum(ndist.max_shard(len(p), world) for p, _ in clouds_np)      # rows of all clouds on one rank
+    est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=min(args.batch, rank_rows), use_graph=args.graph,
                           n_streams=args.streams)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
 
     def step():
-        last = None
         for c in clouds:
             c.build_grid()                                    # search structure: part of the path
-            last = ndist.estimate_sharded(est, c)
-        return last
+        # this rank's row blocks of all clouds as one stream of batches + one all-gather (dist.estimate_sharded_many)
+        return ndist.estimate_sharded_many(est, clouds)[-1]
 
     def sync():
         torch.cuda.synchronize(dev)

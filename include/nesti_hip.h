@@ -192,6 +192,26 @@ int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N
                            float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev,
                            void* stream);
 
+/* Several shapes in flight (BASELINE config 4; also every rank of a multi-GPU job, which holds a block of rows of
+ * every shape): the queries of all items are processed as ONE stream of `batch`-sized batches, so small shapes / small
+ * shards share the gate and expert launches instead of each paying for its own partially filled rounds.  Item i
+ * contributes n_queries rows (as nesti_estimate_normals would for that shape, search grid already built); outputs are the
+ * items' rows concatenated in order: [sum n_queries, 3], [sum], [sum, E].  8^3 Gaussian grid. */
+typedef struct {
+  const float* cloud_dev;        /* [n_points, 3] f32 */
+  int n_points;
+  const int32_t* query_idx_dev;  /* [n_queries] or NULL = rows query_row0 .. query_row0 + n_queries - 1 */
+  int n_queries;
+  double r_abs[NESTI_MAX_SCALES];
+  uint64_t seed;
+  int query_row0;
+  const void* grid_ws_dev;       /* from nesti_patches_grid on this shape */
+  size_t grid_ws_bytes;
+} nesti_shape_queries_t;
+int nesti_estimate_normals_multi(const nesti_model_t* m, const nesti_shape_queries_t* items, int n_items, int batch,
+                                 void* ws_dev, size_t ws_bytes, float* normals_out_dev, int32_t* expert_out_dev,
+                                 float* probs_out_dev, void* stream);
+
 /* ---- text I/O of the file seam (host only) ------------------------------------------------
  * Reading stays np.loadtxt (utils/pcpnet_dataset.py:250): numpy 2's parser is faster than a strtod loop, and the
  * .npy cache the reference writes next to the file makes it a one-off.  The writers are native: np.savetxt's

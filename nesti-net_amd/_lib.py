@@ -18,6 +18,14 @@ class CTensor(ctypes.Structure):
                 ("dims", ctypes.c_int64 * 5)]
 
 
+class CShapeQueries(ctypes.Structure):
+    """Mirror of ``nesti_shape_queries_t``."""
+    _fields_ = [("cloud_dev", ctypes.c_void_p), ("n_points", ctypes.c_int),
+                ("query_idx_dev", ctypes.c_void_p), ("n_queries", ctypes.c_int),
+                ("r_abs", ctypes.c_double * 4), ("seed", ctypes.c_uint64), ("query_row0", ctypes.c_int),
+                ("grid_ws_dev", ctypes.c_void_p), ("grid_ws_bytes", ctypes.c_size_t)]
+
+
 class NestiError(RuntimeError):
     pass
 
@@ -53,6 +61,7 @@ SIGNATURES = {
                                     _vp, _sz, _vp, _vp, _vp, _vp]),
     "nesti_write_text_f32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64, _i]),
     "nesti_write_text_i32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64]),
+    "nesti_estimate_normals_multi": (_i, [_vp, ctypes.POINTER(CShapeQueries), _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "nesti_profile_enable": (_i, [_i]),
     "nesti_profile_read": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     "nesti_model_macs": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),

@@ -32,6 +32,12 @@
 // LDS: [0, 32 KiB) weight slots (3 x k x 2 KiB), [32, 160 KiB) the input chunk; rows are 64 B with the 16-B slot
 // XOR-swizzled by the point index (input) / (row >> 2) & 3 (weights), applied on the DMA source address, which makes
 // every ds_read_b128 lane group conflict-free.  The epilogue reuses the whole 160 KiB as an fp32 staging tile.
+//
+// What did NOT pay (profiles/r02_conv8_experiments.txt): seven re-schedulings of this loop -- waves out of
+// phase, counted vmcnt, hand-counted lgkmcnt with inline-asm reads, adjacent MFMA pairs, K-step-major order, weights
+// straight from L2 into registers without a row barrier, barrier-free rows through LDS counters -- all within +-3 %
+// or slower.  The kernel runs against the chip's power / clock limit: its time follows the MFMAs issued and the operand
+// bits they toggle (zero data: +9 %), which is what the tile layout above reduces.
 #include <type_traits>
 
 #include "kernels.h"

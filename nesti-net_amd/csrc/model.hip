@@ -963,11 +963,11 @@ int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N
                            const double* r_abs, uint64_t seed, int query_row0, int batch, int build_grid,
                            void* grid_ws_dev, size_t grid_ws_bytes, void* ws_dev, size_t ws_bytes,
                            float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, void* stream) {
+  if (M <= 0) return 0;   // no queries: nothing to do
   if (!m || !cloud_dev || !r_abs || !grid_ws_dev || !ws_dev || !normals_out_dev)
     NESTI_FAIL("nesti_estimate_normals: null argument");
   if (N <= 0) NESTI_FAIL("nesti_estimate_normals: empty cloud");
   if (batch <= 0) NESTI_FAIL("nesti_estimate_normals: batch must be positive");
-  if (M <= 0) return 0;
   if (query_row0 < 0 || (!query_idx_dev && (long long)query_row0 + M > (long long)N))
     NESTI_FAIL("nesti_estimate_normals: query rows [query_row0, query_row0 + M) exceed the cloud (N points)");
   if (nesti_estimate_workspace_bytes(m, batch) > ws_bytes)
@@ -1004,6 +1004,66 @@ int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N
         return 1;
       if (nesti_forward(m, points, n_eff, take, fwd_ws, L.total, n_out, e_out, p_out, stream)) return 1;
     }
+  }
+  return 0;
+}
+
+int nesti_estimate_normals_multi(const nesti_model_t* m, const nesti_shape_queries_t* items, int n_items, int batch,
+                                 void* ws_dev, size_t ws_bytes, float* normals_out_dev, int32_t* expert_out_dev,
+                                 float* probs_out_dev, void* stream) {
+  {
+    long long any = 0;
+    for (int i = 0; items && i < n_items; ++i) any += items[i].n_queries > 0 ? items[i].n_queries : 0;
+    if (any == 0) return 0;   // no queries: nothing to do
+  }
+  if (!m || !items || !ws_dev || !normals_out_dev) NESTI_FAIL("nesti_estimate_normals_multi: null argument");
+  if (batch <= 0) NESTI_FAIL("nesti_estimate_normals_multi: batch must be positive");
+  const nesti_config_t* cfg = &m->graph.cfg;
+  if (cfg->grid_n != 8) NESTI_FAIL("nesti_estimate_normals_multi: the 8^3 Gaussian grid only (use nesti_estimate_normals per shape)");
+  if (nesti_estimate_workspace_bytes(m, batch) > ws_bytes)
+    NESTI_FAIL("nesti_estimate_normals_multi: workspace too small (see nesti_estimate_workspace_bytes)");
+  long long total = 0;
+  for (int i = 0; i < n_items; ++i) {
+    const nesti_shape_queries_t& it = items[i];
+    if (it.n_queries < 0 || (it.n_queries > 0 && (!it.cloud_dev || !it.grid_ws_dev || it.n_points <= 0)))
+      NESTI_FAIL("nesti_estimate_normals_multi: bad item");
+    if (it.query_row0 < 0 || (!it.query_idx_dev && (long long)it.query_row0 + it.n_queries > (long long)it.n_points))
+      NESTI_FAIL("nesti_estimate_normals_multi: query rows of an item exceed its cloud");
+    if (it.n_queries > 0 && it.grid_ws_bytes < nesti_patches_workspace_bytes(it.n_points))
+      NESTI_FAIL("nesti_estimate_normals_multi: grid workspace of an item too small");
+    for (int s = 0; s < cfg->n_scales; ++s)
+      if (it.n_queries > 0 && !(it.r_abs[s] > 0.0)) NESTI_FAIL("nesti_estimate_normals_multi: radii must be positive");
+    total += it.n_queries;
+  }
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* fwd_ws = (unsigned char*)ws_dev + est_points_bytes(m, batch) + est_neff_bytes(m, batch);
+  const WsLayout L = ws_layout(m, batch);
+  unsigned char* X0 = fwd_ws + L.x0;
+  const size_t row_bytes = (size_t)nesti_model_mups_rows(m) * m->graph.mups_cstride * dtype_size(m->dtype);   // one query's MuPS
+  const int E = m->graph.cfg.arch == NESTI_ARCH_SWITCH ? 1 : m->graph.cfg.n_experts;
+  long long done = 0;           // rows emitted so far
+  int item = 0, item_done = 0;  // cursor into the items
+  while (done < total) {
+    int fill = 0;
+    const int tok = prof_begin(NESTI_PROF_MUPS, st);
+    while (fill < batch && item < n_items) {
+      const nesti_shape_queries_t& it = items[item];
+      const int take = std::min(batch - fill, it.n_queries - item_done);
+      if (take > 0 &&
+          launch_patches_mups(cfg, it.cloud_dev, it.n_points, it.query_idx_dev ? it.query_idx_dev + item_done : nullptr, take,
+                              it.r_abs, it.seed, it.query_row0 + item_done, it.grid_ws_dev, X0 + (size_t)fill * row_bytes,
+                              m->dtype, m->graph.mups_cstride, nullptr, st))
+        return 1;
+      fill += take;
+      item_done += take;
+      if (item_done >= it.n_queries) { ++item; item_done = 0; }
+    }
+    prof_end(NESTI_PROF_MUPS, tok, st);
+    if (forward_tail(m, X0, fill, fwd_ws, L, normals_out_dev + (size_t)done * 3, expert_out_dev ? expert_out_dev + done : nullptr,
+                     probs_out_dev ? probs_out_dev + (size_t)done * E : nullptr, st))
+      return 1;
+    done += fill;
   }
   return 0;
 }

@@ -133,6 +133,48 @@ class NormalEstimator:
             return normals, None, None
         return normals, expert, probs
 
+    def run_many(self, items):
+        """Several shapes (or shards of shapes) as ONE stream of batches: ``items`` = [(cloud, first, count), ...].
+        Returns one (normals, expert, probs) triple of device tensors per item (views of the concatenated outputs).
+        Small shapes / shards share the gate and expert launches (``nesti_estimate_normals_multi``); results equal
+        ``run`` on each item.  8^3 grid, plain mode; otherwise falls back to per-item ``run``."""
+        if not self._fused or self.cfg.n_gaussians != 8:
+            return [self.run(c, f, n) for c, f, n in items]
+        total = sum(n for _, _, n in items)
+        E = max(1, self.cfg.n_gate_out)
+        single_tower = self.cfg.arch in (ARCH_SINGLE, ARCH_MULTI)
+        normals = torch.empty((total, 3), dtype=torch.float32, device=self.device)
+        expert = torch.empty((total,), dtype=torch.int32, device=self.device)
+        probs = torch.empty((total, E), dtype=torch.float32, device=self.device)
+        arr = (_lib.CShapeQueries * max(1, len(items)))()
+        keep = []
+        for i, (cloud, first, count) in enumerate(items):
+            if first < 0 or count < 0 or first + count > cloud.patch_count:
+                raise ValueError("patch rows [%d, %d) outside [0, %d)" % (first, first + count, cloud.patch_count))
+            qidx = cloud.pidx[first:first + count].contiguous() if cloud.pidx is not None else None
+            keep.append(qidx)
+            arr[i].cloud_dev = cloud.cloud.data_ptr()
+            arr[i].n_points = cloud.n_points
+            arr[i].query_idx_dev = qidx.data_ptr() if qidx is not None and count > 0 else None
+            arr[i].n_queries = count
+            for s, r in enumerate(cloud.r_abs):
+                arr[i].r_abs[s] = r
+            arr[i].seed = cloud.seed
+            arr[i].query_row0 = first
+            arr[i].grid_ws_dev = cloud._ws.data_ptr()
+            arr[i].grid_ws_bytes = cloud._ws.numel()
+        st = torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.net.lib.nesti_estimate_normals_multi(
+                self.net._handle, arr, len(items), self.batch, _lib.ptr(self._arena), self._arena.numel(), _lib.ptr(normals),
+                None if single_tower else _lib.ptr(expert), None if single_tower else _lib.ptr(probs),
+                ctypes.c_void_p(st.cuda_stream)), "nesti_estimate_normals_multi")
+        out, o = [], 0
+        for _, _, n in items:
+            out.append((normals[o:o + n], None if single_tower else expert[o:o + n], None if single_tower else probs[o:o + n]))
+            o += n
+        return out
+
     def estimate(self, pts, pidx=None):
         """Convenience: numpy cloud in, numpy results out (synchronises)."""
         cloud = self.prepare(np.asarray(pts, dtype=np.float32), pidx)

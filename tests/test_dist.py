@@ -40,6 +40,59 @@ def _worker(rank, world, port, n_rows, q):
     dist.destroy_process_group()
 
 
+class _FakeCloud:
+    def __init__(self, n):
+        self.patch_count = n
+
+
+class _FakeEstimator:
+    """run_many of a deterministic function of (cloud size, row): exercises estimate_sharded_many without a GPU."""
+
+    def run_many(self, items):
+        out = []
+        for c, first, count in items:
+            rows = torch.arange(first, first + count, dtype=torch.float32) + 1000.0 * c.patch_count
+            out.append((torch.stack([rows, rows * 2, rows * 3], 1), (torch.arange(first, first + count) % 7).to(torch.int32),
+                        torch.stack([rows + e for e in range(7)], 1)))
+        return out
+
+
+def _worker_many(rank, world, port, sizes, q):
+    import sys
+    sys.path.insert(0, REPO)
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import dist as nd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = nd.estimate_sharded_many(_FakeEstimator(), [_FakeCloud(n) for n in sizes])
+    res2 = nd.estimate_sharded_many(_FakeEstimator(), [_FakeCloud(n) for n in sizes])      # buffers reused
+    assert all(torch.equal(a[0], b[0]) for a, b in zip(res, res2))
+    q.put((rank, [(n.numpy(), e.numpy(), p.numpy()) for n, e, p in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_many_two_ranks_gloo():
+    """One all-gather for several clouds of different (ragged) sizes: every rank ends up with every cloud in row order."""
+    sizes, world = [1001, 64, 500], 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_many, args=(r, world, port, sizes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, clouds in res:
+        for n_rows, (n, e, p) in zip(sizes, clouds):
+            rows = np.arange(n_rows, dtype=np.float32) + 1000.0 * n_rows
+            assert np.array_equal(n, np.stack([rows, rows * 2, rows * 3], 1))
+            assert np.array_equal(e, (np.arange(n_rows) % 7).astype(np.int32))
+            assert np.array_equal(p[:, 6], rows + 6)
+
+
 def test_shard_ranges_cover_everything():
     import nesti_net_amd  # noqa: F401
     from nesti_net_amd import dist as nd
