@@ -31,7 +31,9 @@ from nesti_net_amd import dist as ndist  # noqa: E402
 from nesti_net_amd.config import NestiConfig  # noqa: E402
 from nesti_net_amd.pipeline import NormalEstimator  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md (bf16x3 issues 3 bf16 MFMAs per
+#                                                                               algorithmic multiply; the numerator stays algorithmic)
+MAX_BATCH = {"bf16x3": 32768, "f32": 8192}   # library batch caps by workspace: 3 planes / 4-byte activations
 
 
 def make_clouds(n_clouds, n_points, stream=False):
@@ -175,8 +177,8 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     results for its shard of cloud 0 (for the parity leg) and the model's MAC counts."""
     lib = _lib.load()
     rank_rows = sum(ndist.max_shard(len(p), world) for p, _ in clouds_np)      # rows of all clouds on one rank
-    est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=min(args.batch, rank_rows), use_graph=args.graph,
-                          n_streams=args.streams)
+    est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=min(args.batch, rank_rows, MAX_BATCH.get(dtype, 1 << 30)),
+                          use_graph=args.graph, n_streams=args.streams)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
 
     def step():
@@ -257,7 +259,7 @@ def main():
                     help="queries per library call (workspace ~1.7 MB per query in f16: a whole 100k-point cloud is one batch; "
                          "+1.5 %% from 25 000 to 50 000 and +1.2 %% more to 100 000 -- the per-expert launches fill the chip in "
                          "fewer, fuller rounds)")
-    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "f32"],
+    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "bf16x3", "f32"],
                     help="f16 (default) meets the north star's 1e-5 cosine tolerance against the fp32 mode; bf16 does not")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")

@@ -31,8 +31,11 @@ extern "C" {
 #define NESTI_MAX_EXPERTS 8
 #define NESTI_MUPS_CH 20 /* channels per scale: utils/tf_util.py:711-720 */
 
-/* element types for activations / weights */
-enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2 };
+/* element types for activations / weights.  NESTI_BF16X3 is a MODEL dtype only (nesti_model_create): activations and
+ * weights are kept as a bf16 (hi, lo) pair, v ~ hi + lo to 2^-17 relative, and every multiply is the three bf16 MFMA
+ * products hi*hi + lo*hi + hi*lo accumulated in fp32 -- the mode that meets the 1e-5 cosine / arg-max tolerance of
+ * test_n_est_w_experts.py's outputs at a third of the bf16 rate instead of the fp32 MFMA rate. */
+enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3 };
 
 /* which graph nesti_model_create builds */
 enum {

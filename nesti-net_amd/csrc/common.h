@@ -27,6 +27,13 @@ void set_error(const std::string& msg);
   } while (0)
 
 static inline size_t dtype_size(int dt) { return dt == NESTI_F32 ? 4 : 2; }
+// NESTI_BF16X3: the kernels are the bf16 ones; an activation row holds, per group of 64 channels, the three 64-element
+// planes [hi | lo | hi] (192 elements), and the packed weights the matching K order [W_hi ; W_hi ; W_lo], so that the
+// unchanged K loop accumulates hi*W_hi + lo*W_hi + hi*W_lo.  Writers emit the planes (split_col / split_pack2 below).
+static inline int kernel_dtype(int dt) { return dt == NESTI_BF16X3 ? NESTI_BF16 : dt; }
+static inline int act_planes(int dt) { return dt == NESTI_BF16X3 ? 3 : 1; }
+constexpr int kSplitGroup = 64;
+__host__ __device__ __forceinline__ int split_col(int col) { return (col >> 6) * (3 * kSplitGroup) + (col & (kSplitGroup - 1)); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- element conversion (device) ------------------------------------------
@@ -71,6 +78,51 @@ template <> struct Elem<NESTI_F16> {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((nesti_f32x2){lo, hi}, nesti_f16x2));
   }
 };
+
+// (hi, lo) bf16 pair of two values: hi = rne(v), lo = rne(v - hi) (v - hi is exact in fp32)
+__device__ __forceinline__ void split_pack2(float a, float b, uint32_t& hi, uint32_t& lo) {
+  hi = Elem<NESTI_BF16>::pack2(a, b);
+  lo = Elem<NESTI_BF16>::pack2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+// the value a (hi, lo) pair stands for
+__device__ __forceinline__ float split_join(uint16_t hi, uint16_t lo) { return bf16_bits_to_f32(hi) + bf16_bits_to_f32(lo); }
+
+// Four / eight consecutive 16-bit channels of one activation row, starting at LOGICAL column col (a multiple of 4 / 8,
+// so a vector never straddles a 64-channel group); row_elems = row * physical channel stride.
+template <class E>
+__device__ __forceinline__ void store_act4(unsigned char* base, long long row_elems, int col, float a, float b, float c, float d, int split) {
+  if (!split) {
+    *reinterpret_cast<uint2*>(base + (row_elems + col) * 2) = make_uint2(E::pack2(a, b), E::pack2(c, d));
+    return;
+  }
+  uint32_t h0, l0, h1, l1;
+  split_pack2(a, b, h0, l0);
+  split_pack2(c, d, h1, l1);
+  unsigned char* d0 = base + (row_elems + split_col(col)) * 2;
+  *reinterpret_cast<uint2*>(d0) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(d0 + 2 * kSplitGroup) = make_uint2(l0, l1);
+  *reinterpret_cast<uint2*>(d0 + 4 * kSplitGroup) = make_uint2(h0, h1);
+}
+template <class E>
+__device__ __forceinline__ void store_act8(unsigned char* base, long long row_elems, int col, const float4& f0, const float4& f1, int split) {
+  if (!split) {
+    *reinterpret_cast<uint4*>(base + (row_elems + col) * 2) =
+        make_uint4(E::pack2(f0.x, f0.y), E::pack2(f0.z, f0.w), E::pack2(f1.x, f1.y), E::pack2(f1.z, f1.w));
+    return;
+  }
+  uint4 h, l;
+  split_pack2(f0.x, f0.y, h.x, l.x);
+  split_pack2(f0.z, f0.w, h.y, l.y);
+  split_pack2(f1.x, f1.y, h.z, l.z);
+  split_pack2(f1.z, f1.w, h.w, l.w);
+  unsigned char* d0 = base + (row_elems + split_col(col)) * 2;
+  *reinterpret_cast<uint4*>(d0) = h;
+  *reinterpret_cast<uint4*>(d0 + 2 * kSplitGroup) = l;
+  *reinterpret_cast<uint4*>(d0 + 4 * kSplitGroup) = h;
+}
+
+// NESTI_BF16X3 as a store type (mups.hip): bf16 elements, three planes
+template <> struct Elem<NESTI_BF16X3> : Elem<NESTI_BF16> {};
 
 // host-side conversions used by the weight repacker
 uint16_t host_f32_to_bf16(float f);

@@ -333,12 +333,12 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
                               fmaxf(sum[x].z * inv + bb.z, act_floor), fmaxf(sum[x].w * inv + bb.w, act_floor)};
           const long long gr = r0 + row0 + x;
           if (gr < total_rows) {
-            unsigned char* dst = out_b + (gr * p.out_cstride + out_col0 + nh * 64 + cg * 4) * out_esz;
+            const int col = out_col0 + nh * 64 + cg * 4;
             if (out_esz == 4) {
-              *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+              *reinterpret_cast<float4*>(out_b + (gr * p.out_cstride + col) * 4) = make_float4(o[0], o[1], o[2], o[3]);
             } else {
               using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
-              *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(o[0], o[1]), E::pack2(o[2], o[3]));
+              store_act4<E>(out_b, gr * p.out_cstride, col, o[0], o[1], o[2], o[3], p.split);
             }
           }
         }
@@ -404,12 +404,12 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
     // 4-channel group.  max(relu(x + b)) is taken on the final values, exactly like pooling the stored tensor.
     unsigned char* mp_b = reinterpret_cast<unsigned char*>(p.mp_out);
     const int Vo = V >> 3, So = S >> 1, log2So = log2S - 1;
-    auto cvt_store = [&](unsigned char* dst, const float4& v) __attribute__((always_inline)) {
+    auto cvt_store = [&](unsigned char* base, long long row_elems, int col, const float4& v) __attribute__((always_inline)) {
       if (out_esz == 4) {
-        *reinterpret_cast<float4*>(dst) = v;
+        *reinterpret_cast<float4*>(base + (row_elems + col) * 4) = v;
       } else {
         using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
-        *reinterpret_cast<uint2*>(dst) = make_uint2(E::pack2(v.x, v.y), E::pack2(v.z, v.w));
+        store_act4<E>(base, row_elems, col, v.x, v.y, v.z, v.w, p.split);
       }
     };
     auto mp_half = [&](auto NH) __attribute__((always_inline)) {
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           const int row = item >> 4, cg = item & 15;
           const long long gr = r0 + row;
           if (gr < total_rows)
-            cvt_store(out_b + (gr * p.out_cstride + out_col0 + nh * 64 + cg * 4) * out_esz,
+            cvt_store(out_b, gr * p.out_cstride, out_col0 + nh * 64 + cg * 4,
                       *reinterpret_cast<const float4*>(smem + row * kPoolStride + cg * 16));
         }
       }
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
         }
         const long long go = (r0 >> 3) + orow;
         if (go < (total_rows >> 3))
-          cvt_store(mp_b + (go * p.mp_cstride + out_col0 + nh * 64 + cg * 4) * out_esz, m);
+          cvt_store(mp_b, go * p.mp_cstride, out_col0 + nh * 64 + cg * 4, m);
       }
       __syncthreads();
     };
@@ -498,10 +498,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           const int row = it * 8 + (lane >> 3), cpos = lane & 7;
           const float4 f0 = *reinterpret_cast<const float4*>(scratch + row * kPoolStride + cpos * 32);
           const float4 f1 = *reinterpret_cast<const float4*>(scratch + row * kPoolStride + cpos * 32 + 16);
-          const uint4 v = make_uint4(E::pack2(f0.x, f0.y), E::pack2(f0.z, f0.w), E::pack2(f1.x, f1.y), E::pack2(f1.z, f1.w));
           const long long gr = r0 + tile_row(remap, log2S, wave, mi, row);
-          if (gr < total_rows)
-            *reinterpret_cast<uint4*>(out_b + (gr * p.out_cstride + out_col0 + nh * 64) * 2 + cpos * 16) = v;
+          if (gr < total_rows) store_act8<E>(out_b, gr * p.out_cstride, out_col0 + nh * 64 + cpos * 8, f0, f1, p.split);
         }
       }
     }

@@ -273,13 +273,14 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
   const int out_col0 = p.out_coff + n_tile * 32;
   unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
   unsigned char* mp_b = reinterpret_cast<unsigned char*>(p.mp_out);
-  auto cvt_store8 = [&](unsigned char* dst, const float4& f0, const float4& f1) __attribute__((always_inline)) {
+  auto cvt_store8 = [&](unsigned char* base, long long row_elems, int col, const float4& f0, const float4& f1) __attribute__((always_inline)) {
     if (out_esz == 4) {
-      reinterpret_cast<float4*>(dst)[0] = f0;
-      reinterpret_cast<float4*>(dst)[1] = f1;
+      float4* dst = reinterpret_cast<float4*>(base + (row_elems + col) * 4);
+      dst[0] = f0;
+      dst[1] = f1;
     } else {
       using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
-      *reinterpret_cast<uint4*>(dst) = make_uint4(E::pack2(f0.x, f0.y), E::pack2(f0.z, f0.w), E::pack2(f1.x, f1.y), E::pack2(f1.z, f1.w));
+      store_act8<E>(base, row_elems, col, f0, f1, p.split);
     }
   };
   auto epi_pass = [&](auto HH) __attribute__((always_inline)) {
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
         if (ptl < np_here) {
           const float4 f0 = *reinterpret_cast<const float4*>(smem + row * kEpiStride + seg * 32);
           const float4 f1 = *reinterpret_cast<const float4*>(smem + row * kEpiStride + seg * 32 + 16);
-          cvt_store8(out_b + (((size_t)(p0 + ptl) * 512 + vox) * p.out_cstride + out_col0 + seg * 8) * out_esz, f0, f1);
+          cvt_store8(out_b, ((long long)(p0 + ptl) * 512 + vox) * p.out_cstride, out_col0 + seg * 8, f0, f1);
         }
       }
     }
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
       }
       if (ptl < np_here) {
         const int ovox = ((2 * hh + cz) * 4 + cy) * 4 + cx;
-        cvt_store8(mp_b + (((size_t)(p0 + ptl) * 64 + ovox) * p.mp_cstride + out_col0 + seg * 8) * out_esz, m0, m1);
+        cvt_store8(mp_b, ((long long)(p0 + ptl) * 64 + ovox) * p.mp_cstride, out_col0 + seg * 8, m0, m1);
       }
     }
     __syncthreads();

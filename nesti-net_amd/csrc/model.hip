@@ -513,6 +513,10 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
         ++pl->n_taps;
       }
   const size_t esz = dtype_size(dtype);
+  // NESTI_BF16X3 (common.h): K runs over the physical input row -- per 64-channel group the planes [hi | lo | hi] -- and
+  // the weights follow it as [W_hi ; W_hi ; W_lo], so the unchanged K loop accumulates hi*W_hi + lo*W_hi + hi*W_lo
+  const int planes = act_planes(dtype);
+  const int K_phys = d.Cin_p * planes;
   pl->kind = use_conv8(d) ? 1 : 0;
   const int row_bytes = pl->kind == 1 ? 64 : kRowBytes;   // bytes of one K chunk of one row
   const int KC = row_bytes / (int)esz;
@@ -520,8 +524,8 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
   pl->n_tiles = d.Cout_p / pl->TN;
   pl->split_tile = part_p / pl->TN * (n_parts == 2 ? 1 : n_parts);
   if (n_parts == 1) pl->split_tile = pl->n_tiles;
-  pl->n_chunks = d.Cin_p / KC;
-  if (d.Cin_p % KC) NESTI_FAIL("internal: Cin_p not a multiple of the K chunk");
+  pl->n_chunks = K_phys / KC;
+  if (K_phys % KC || d.Cin_p % kSplitGroup) NESTI_FAIL("internal: Cin_p not a multiple of the K chunk");
   if (n_parts == 2 && pl->n_taps != 1) NESTI_FAIL("internal: fused layers must be 1x1x1");
   std::vector<int> inv(d.Cin_p, -1);
   for (int c = 0; c < d.cin; ++c) inv[d.in_pos[c]] = c;
@@ -538,7 +542,9 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
         unsigned char* tile = host.data() + (((size_t)nt * pl->n_chunks + ch) * pl->n_taps + t) * tile_bytes;
         const float* wt = f.w + (size_t)tap_widx[t] * d.cin * d.cout;
         for (int kc = 0; kc < KC; ++kc) {
-          const int cr = inv[ch * KC + kc];
+          const int q = ch * KC + kc;                        // physical K position
+          const int plane = planes == 1 ? 0 : (q % (3 * kSplitGroup)) / kSplitGroup;
+          const int cr = inv[planes == 1 ? q : (q / (3 * kSplitGroup)) * kSplitGroup + q % kSplitGroup];
           if (cr < 0) continue;
           const float* wrow = wt + (size_t)cr * d.cout;
           const int slot = kc / per_slot, within = kc % per_slot;
@@ -551,7 +557,16 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
                 ? tile + (size_t)nl * 64 + ((slot ^ ((nl >> 2) & 3)) << 4) + within * esz
                 : tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
             if (dtype == NESTI_F32) memcpy(dst, &v, 4);
-            else {
+            else if (dtype == NESTI_BF16X3) {
+              uint16_t h = host_f32_to_bf16(v);
+              if (plane == 2) {                              // W_lo = rne(W - W_hi)
+                const uint32_t hb = (uint32_t)h << 16;
+                float hf;
+                memcpy(&hf, &hb, 4);
+                h = host_f32_to_bf16(v - hf);
+              }
+              memcpy(dst, &h, 2);
+            } else {
               const uint16_t h = (dtype == NESTI_BF16) ? host_f32_to_bf16(v) : host_f32_to_f16(v);
               memcpy(dst, &h, 2);
             }
@@ -573,7 +588,7 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
 // workspace planning and tower execution
 // ------------------------------------------------------------------------------------------
 size_t buf_bytes(const BufSpec& b, int NB, int dtype) {
-  const size_t e = b.f32 ? 4 : dtype_size(dtype);
+  const size_t e = b.f32 ? 4 : dtype_size(dtype) * act_planes(dtype);
   return align_up(((size_t)NB << (3 * b.log2S)) * b.C * e, 256);
 }
 // Workspace placement of a tower's buffers: a buffer lives from the first launch that writes it to the last launch that
@@ -672,14 +687,18 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf]; p.wpk = pl.wpk; p.bias = pl.bias;
       p.npoints_ptr = rc.npoints_ptr; p.point_index = ext_in ? rc.point_index : nullptr;
       p.npoints = rc.NB;
-      p.in_cstride = op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
-      p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
+      // NESTI_BF16X3: strides and the input offset are physical (a 64-aligned logical offset x 3), output column
+      // offsets stay logical (kernels.h: ConvParams::split); an fp32 output buffer is an ordinary one
+      const int planes = act_planes(dtype);
+      p.split = planes > 1 ? 1 : 0;
+      p.in_cstride = (op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C) * planes; p.in_coff = op.in_coff * planes;
+      p.out_cstride = T.bufs[op.out_buf].C * (op.out_f32 ? 1 : planes); p.out_coff = op.out_coff;
       p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S; p.s_real = d.s_real;
       p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
       const long long rows = (long long)rc.NB << (3 * d.log2S);
       p.m_tiles = pl.kind == 1 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
-      if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C; p.mp_mode = op.mp_mode; }
+      if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C * planes; p.mp_mode = op.mp_mode; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
       if (pl.kind == 1) {   // conv8_kernel: feature bits for same-box A/B runs (bit 0: early staging of the next chunk)
@@ -687,7 +706,8 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
         p.remap = flags;
       }
       const int tok = prof_begin(NESTI_PROF_CONV, rc.stream);
-      const int rcv = pl.kind == 1 ? launch_conv8(p, dtype, d.k, rc.stream) : launch_conv(p, dtype, pl.TN, rc.stream);
+      const int rcv = pl.kind == 1 ? launch_conv8(p, kernel_dtype(dtype), d.k, rc.stream)
+                                   : launch_conv(p, kernel_dtype(dtype), pl.TN, rc.stream);
       prof_end(NESTI_PROF_CONV, tok, rc.stream);
       if (rcv) return 1;
     } else {
@@ -696,11 +716,14 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf];
       p.npoints_ptr = rc.npoints_ptr;
       p.npoints = rc.NB;
-      p.in_cstride = T.bufs[op.in_buf].C; p.in_coff = op.in_coff;
-      p.out_cstride = T.bufs[op.out_buf].C; p.out_coff = op.out_coff;
+      const int planes = act_planes(dtype);
+      p.split = planes > 1 ? 1 : 0;
+      p.in_cstride = T.bufs[op.in_buf].C * planes; p.in_coff = op.in_coff;
+      p.out_cstride = T.bufs[op.out_buf].C * planes; p.out_coff = op.out_coff;
       p.C = op.C; p.log2S = op.log2S;
       const int tok = prof_begin(NESTI_PROF_POOL, rc.stream);
-      const int rcp = op.kind == Op::MAX3 ? launch_maxpool3s2(p, dtype, rc.stream) : launch_maxpool2(p, dtype, rc.stream);
+      const int rcp = op.kind == Op::MAX3 ? launch_maxpool3s2(p, kernel_dtype(dtype), rc.stream)
+                                          : launch_maxpool2(p, kernel_dtype(dtype), rc.stream);
       prof_end(NESTI_PROF_POOL, tok, rc.stream);
       if (rcp) return 1;
     }
@@ -708,6 +731,9 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
   *out = reinterpret_cast<float*>(ptr[T.out_buf]);
   return 0;
 }
+
+// channel stride of the MuPS rows the towers read, in elements (NESTI_BF16X3: three planes per 64-channel group)
+int mups_stride(const nesti_model* m) { return m->graph.mups_cstride * act_planes(m->dtype); }
 
 size_t max_tower_bytes(const nesti_model* m, int NB) {
   size_t t = tower_bytes(m->graph.gate, NB, m->dtype);
@@ -720,7 +746,7 @@ struct WsLayout {
 };
 WsLayout ws_layout(const nesti_model* m, int NB) {
   WsLayout L;
-  const size_t act = align_up(((size_t)NB << (3 * m->graph.gate_x0_log2S())) * m->graph.mups_cstride * dtype_size(m->dtype), 256);
+  const size_t act = align_up(((size_t)NB << (3 * m->graph.gate_x0_log2S())) * mups_stride(m) * dtype_size(m->dtype), 256);
   size_t o = 0;
   L.x0 = o; o += act;
   L.probs = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
@@ -844,7 +870,7 @@ int nesti_model_describe(const nesti_config_t* cfg, int* n_tensors, nesti_tensor
 int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors, int n_tensors, int dtype,
                        nesti_model_t** out) {
   if (!cfg || !tensors || !out) NESTI_FAIL("nesti_model_create: null argument");
-  if (dtype != NESTI_F32 && dtype != NESTI_BF16 && dtype != NESTI_F16) NESTI_FAIL("nesti_model_create: bad dtype");
+  if (dtype != NESTI_F32 && dtype != NESTI_BF16 && dtype != NESTI_F16 && dtype != NESTI_BF16X3) NESTI_FAIL("nesti_model_create: bad dtype");
   std::unique_ptr<nesti_model> m(new nesti_model());
   m->dtype = dtype;
   if (build_graph(cfg, &m->graph)) return 1;
@@ -865,7 +891,7 @@ size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch) {
   return ws_layout(m, max_batch).total;
 }
 
-int nesti_model_mups_cstride(const nesti_model_t* m) { return m ? m->graph.mups_cstride : 0; }
+int nesti_model_mups_cstride(const nesti_model_t* m) { return m ? nesti::mups_stride(m) : 0; }
 int nesti_model_mups_rows(const nesti_model_t* m) { return m ? 1 << (3 * m->graph.gate_x0_log2S()) : 0; }
 
 int nesti_model_mups(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B, void* mups_out_dev,
@@ -873,7 +899,7 @@ int nesti_model_mups(const nesti_model_t* m, const float* points_dev, const int3
   if (B <= 0) return 0;
   if (!m || !points_dev || !n_eff_dev || !mups_out_dev) NESTI_FAIL("nesti_model_mups: null argument");
   const int tok = prof_begin(NESTI_PROF_MUPS, (hipStream_t)stream);
-  const int rc = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, mups_out_dev, m->dtype, m->graph.mups_cstride,
+  const int rc = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, mups_out_dev, m->dtype, mups_stride(m),
                              /*embed4=*/m->graph.cfg.grid_n == 3, (hipStream_t)stream);
   prof_end(NESTI_PROF_MUPS, tok, (hipStream_t)stream);
   return rc;
@@ -936,7 +962,7 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
   hipStream_t st = (hipStream_t)stream;
   void* X0 = ws + L.x0;
   const int tok = prof_begin(NESTI_PROF_MUPS, st);
-  const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, m->graph.mups_cstride,
+  const int rcm = launch_mups(&m->graph.cfg, points_dev, n_eff_dev, B, X0, m->dtype, mups_stride(m),
                               /*embed4=*/m->graph.cfg.grid_n == 3, st);
   prof_end(NESTI_PROF_MUPS, tok, st);
   if (rcm) return 1;
@@ -994,7 +1020,7 @@ int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N
     if (fused) {
       const int tok = prof_begin(NESTI_PROF_MUPS, st);
       const int rcf = launch_patches_mups(cfg, cloud_dev, N, qidx, take, r_abs, seed, query_row0 + done, grid_ws_dev,
-                                          fwd_ws + L.x0, m->dtype, m->graph.mups_cstride, n_eff, st);
+                                          fwd_ws + L.x0, m->dtype, mups_stride(m), n_eff, st);
       prof_end(NESTI_PROF_MUPS, tok, st);
       if (rcf) return 1;
       if (forward_tail(m, fwd_ws + L.x0, take, fwd_ws, L, n_out, e_out, p_out, st)) return 1;
@@ -1040,7 +1066,7 @@ int nesti_estimate_normals_multi(const nesti_model_t* m, const nesti_shape_queri
   unsigned char* fwd_ws = (unsigned char*)ws_dev + est_points_bytes(m, batch) + est_neff_bytes(m, batch);
   const WsLayout L = ws_layout(m, batch);
   unsigned char* X0 = fwd_ws + L.x0;
-  const size_t row_bytes = (size_t)nesti_model_mups_rows(m) * m->graph.mups_cstride * dtype_size(m->dtype);   // one query's MuPS
+  const size_t row_bytes = (size_t)nesti_model_mups_rows(m) * mups_stride(m) * dtype_size(m->dtype);   // one query's MuPS
   const int E = m->graph.cfg.arch == NESTI_ARCH_SWITCH ? 1 : m->graph.cfg.n_experts;
   long long done = 0;           // rows emitted so far
   int item = 0, item_done = 0;  // cursor into the items
@@ -1053,7 +1079,7 @@ int nesti_estimate_normals_multi(const nesti_model_t* m, const nesti_shape_queri
       if (take > 0 &&
           launch_patches_mups(cfg, it.cloud_dev, it.n_points, it.query_idx_dev ? it.query_idx_dev + item_done : nullptr, take,
                               it.r_abs, it.seed, it.query_row0 + item_done, it.grid_ws_dev, X0 + (size_t)fill * row_bytes,
-                              m->dtype, m->graph.mups_cstride, nullptr, st))
+                              m->dtype, mups_stride(m), nullptr, st))
         return 1;
       fill += take;
       item_done += take;

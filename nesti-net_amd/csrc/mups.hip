@@ -99,21 +99,42 @@ __device__ __forceinline__ float signed_sqrt(float v) {   // utils/tf_util.py:73
   return copysignf(sqrtf(fabsf(v)), v);
 }
 
+// the 20 channels of one scale of one Gaussian row; row_off = row * channel stride (physical), col0 = 20 s (logical)
 template <int DT>
-__device__ __forceinline__ void store20(void* out, size_t elem_off, const float (&v)[20]) {
+__device__ __forceinline__ void store20(void* out, size_t row_off, int col0, const float (&v)[20]) {
   using E = Elem<DT>;
   if constexpr (DT == NESTI_F32) {
-    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + elem_off);
+    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + row_off + col0);
 #pragma unroll
     for (int q = 0; q < 5; ++q) p[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  } else if constexpr (DT == NESTI_BF16X3) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      store_act4<E>(reinterpret_cast<unsigned char*>(out), (long long)row_off, col0 + 4 * q, v[4 * q], v[4 * q + 1], v[4 * q + 2],
+                    v[4 * q + 3], 1);
   } else {
-    uint2* p = reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + elem_off);
+    uint2* p = reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(out) + row_off + col0);
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
       uint32_t lo = (uint32_t)E::from_f32(v[4 * q]) | ((uint32_t)E::from_f32(v[4 * q + 1]) << 16);
       uint32_t hi = (uint32_t)E::from_f32(v[4 * q + 2]) | ((uint32_t)E::from_f32(v[4 * q + 3]) << 16);
       p[q] = make_uint2(lo, hi);
     }
+  }
+}
+// zeros in the padding channels of one row: logical columns [pad0, width) -- for NESTI_BF16X3 in each of the three planes
+// of every 64-channel group (cstride is the physical stride, 3 x the logical width)
+template <int DT>
+__device__ __forceinline__ void zero_pad_row(void* out, size_t row_off, int pad0, int cstride) {
+  using E = Elem<DT>;
+  typename E::T* o = reinterpret_cast<typename E::T*>(out) + row_off;
+  if constexpr (DT == NESTI_BF16X3) {
+    for (int c = 0; c < cstride; ++c) {
+      const int logical = (c / (3 * kSplitGroup)) * kSplitGroup + (c & (kSplitGroup - 1));
+      if (logical >= pad0) o[c] = 0;
+    }
+  } else {
+    for (int c = pad0; c < cstride; ++c) o[c] = E::from_f32(0.f);
   }
 }
 
@@ -162,14 +183,14 @@ __device__ __forceinline__ void mups_one_scale(MupsShared& sh, Coord coord, int 
   const int lane = t & 63, wave = t >> 6;
   const int g0 = 64 * i0 + 8 * j + k;
   const int g1 = g0 + 256;
-  const size_t o0 = ((size_t)b * kG + g0) * cstride + 20 * s;
-  const size_t o1 = ((size_t)b * kG + g1) * cstride + 20 * s;
+  const size_t o0 = ((size_t)b * kG + g0) * cstride;
+  const size_t o1 = ((size_t)b * kG + g1) * cstride;
   if (m <= 0) {   // zero-padded batch tail (test_n_est_w_experts.py:134-140): skip, do not divide by 0
     float z[20];
 #pragma unroll
     for (int c = 0; c < 20; ++c) z[c] = 0.f;
-    store20<DT>(out, o0, z);
-    store20<DT>(out, o1, z);
+    store20<DT>(out, o0, 20 * s, z);
+    store20<DT>(out, o1, 20 * s, z);
     return;
   }
   // rows 0..m are unmasked: `mask = r > n_eff` (utils/tf_util.py:693), so row m -- normally the
@@ -262,23 +283,19 @@ __device__ __forceinline__ void mups_one_scale(MupsShared& sh, Coord coord, int 
     v0[c] *= inv;
     v1[c] *= inv;
   }
-  store20<DT>(out, o0, v0);
-  store20<DT>(out, o1, v1);
+  store20<DT>(out, o0, 20 * s, v0);
+  store20<DT>(out, o1, 20 * s, v1);
 }
 
 // zero the padding channels [20*S, cstride) of this thread's two output rows so downstream GEMMs can read whole rows
 template <int DT>
 __device__ __forceinline__ void mups_zero_pad(void* __restrict__ out, int b, int S, int cstride, int t) {
   const int pad0 = 20 * S;
-  if (pad0 < cstride) {
+  if (pad0 < cstride / (DT == NESTI_BF16X3 ? 3 : 1)) {
     const int k = t & 7, j = (t >> 3) & 7, i0 = t >> 6;
     const int g0 = 64 * i0 + 8 * j + k, g1 = g0 + 256;
-    using E = Elem<DT>;
-    typename E::T* o = reinterpret_cast<typename E::T*>(out);
-    for (int c = pad0; c < cstride; ++c) {
-      o[((size_t)b * kG + g0) * cstride + c] = E::from_f32(0.f);
-      o[((size_t)b * kG + g1) * cstride + c] = E::from_f32(0.f);
-    }
+    zero_pad_row<DT>(out, ((size_t)b * kG + g0) * cstride, pad0, cstride);
+    zero_pad_row<DT>(out, ((size_t)b * kG + g1) * cstride, pad0, cstride);
   }
 }
 
@@ -341,17 +358,15 @@ __global__ __launch_bounds__(64) void mups3_kernel(const float* __restrict__ poi
   const int gi = t / 9, gj = (t / 3) % 3, gk = t % 3;
   const int rows_pp = embed ? 64 : 27;
   const int row = embed ? 16 * gi + 4 * gj + gk : t;
-  using E = Elem<DT>;
-  typename E::T* o = reinterpret_cast<typename E::T*>(out);
   const float mus[3] = {mu0, mu1, mu2};
   for (int s = 0; s < S; ++s) {
     const int m = n_eff[(size_t)b * S + s];
-    const size_t o0 = ((size_t)b * rows_pp + row) * cstride + 20 * s;
+    const size_t o0 = ((size_t)b * rows_pp + row) * cstride;
     float v[20];
     if (m <= 0) {     // zero-padded batch tail: skip, do not divide by 0
 #pragma unroll
       for (int c = 0; c < 20; ++c) v[c] = 0.f;
-      if (own) store20<DT>(out, o0, v);
+      if (own) store20<DT>(out, o0, 20 * s, v);
       continue;
     }
     const int nrows = min(m + 1, P);               // mask = r > n_eff (utils/tf_util.py:693)
@@ -417,13 +432,13 @@ __global__ __launch_bounds__(64) void mups3_kernel(const float* __restrict__ poi
     if (own) {
 #pragma unroll
       for (int c = 0; c < 20; ++c) v[c] *= 1.0f / sqrtf(fmaxf(norm2[c], 1e-12f));
-      store20<DT>(out, o0, v);
+      store20<DT>(out, o0, 20 * s, v);
     }
   }
   // padding channels [20 S, cstride) of the owned rows, and (embedded layout) the whole dead rows: zeros
   for (int r = t; r < rows_pp; r += 64) {
     const bool dead = embed && (((r >> 4) & 3) == 3 || ((r >> 2) & 3) == 3 || (r & 3) == 3);
-    for (int c = dead ? 0 : 20 * S; c < cstride; ++c) o[((size_t)b * rows_pp + r) * cstride + c] = E::from_f32(0.f);
+    zero_pad_row<DT>(out, ((size_t)b * rows_pp + r) * cstride, dead ? 0 : 20 * S, cstride);
   }
 }
 
@@ -433,9 +448,11 @@ int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n
                 void* out, int out_dtype, int out_cstride, int embed4, hipStream_t stream) {
   if (cfg->grid_n != kR && cfg->grid_n != 3) NESTI_FAIL("nesti_mups_forward: the Gaussian grid must be 8^3 or 3^3");
   if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("nesti_mups_forward: bad n_scales");
-  if (out_cstride < 20 * cfg->n_scales || (out_cstride % 4) != 0)
+  const bool x3 = out_dtype == NESTI_BF16X3;   // three planes per 64-channel group: out_cstride is the physical stride
+  if (x3 && out_cstride % (3 * kSplitGroup)) NESTI_FAIL("nesti_mups_forward: a bf16x3 row is a whole number of 192-element groups");
+  if (out_cstride / (x3 ? 3 : 1) < 20 * cfg->n_scales || (out_cstride % 4) != 0)
     NESTI_FAIL("nesti_mups_forward: out_cstride must be >= 20*S and a multiple of 4");
-  if (out_dtype != NESTI_F32 && out_dtype != NESTI_BF16 && out_dtype != NESTI_F16) NESTI_FAIL("nesti_mups_forward: unknown out_dtype");
+  if (out_dtype != NESTI_F32 && out_dtype != NESTI_BF16 && out_dtype != NESTI_F16 && !x3) NESTI_FAIL("nesti_mups_forward: unknown out_dtype");
   if (B <= 0) return 0;
   const float sigma = (float)sqrt(cfg->variance);     // np.sqrt in f64, then the f32 placeholder: test_n_est_w_experts.py:146
   const int S = cfg->n_scales, P = cfg->points_per_scale;
@@ -449,6 +466,8 @@ int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n
       hipLaunchKernelGGL(mups3_kernel<NESTI_F32>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w, mu0, mu1, mu2, embed4);
     else if (out_dtype == NESTI_BF16)
       hipLaunchKernelGGL(mups3_kernel<NESTI_BF16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w, mu0, mu1, mu2, embed4);
+    else if (x3)
+      hipLaunchKernelGGL(mups3_kernel<NESTI_BF16X3>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w, mu0, mu1, mu2, embed4);
     else
       hipLaunchKernelGGL(mups3_kernel<NESTI_F16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w, mu0, mu1, mu2, embed4);
     NESTI_CHECK_HIP(hipGetLastError());
@@ -460,6 +479,8 @@ int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n
     hipLaunchKernelGGL(mups_kernel<NESTI_F32>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w);
   else if (out_dtype == NESTI_BF16)
     hipLaunchKernelGGL(mups_kernel<NESTI_BF16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w);
+  else if (x3)
+    hipLaunchKernelGGL(mups_kernel<NESTI_BF16X3>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w);
   else
     hipLaunchKernelGGL(mups_kernel<NESTI_F16>, grid, block, 0, stream, points, n_eff, B, S, P, out, out_cstride, sigma, w);
   NESTI_CHECK_HIP(hipGetLastError());
@@ -471,7 +492,9 @@ int launch_patches_mups(const nesti_config_t* cfg, const float* cloud_dev, int N
                         int out_cstride, int32_t* n_eff_out_dev, hipStream_t stream) {
   if (cfg->grid_n != kR) NESTI_FAIL("launch_patches_mups: the fused kernel serves the 8^3 Gaussian grid");
   if (cfg->points_per_scale < 1 || 2 * cfg->points_per_scale > kListCap) NESTI_FAIL("launch_patches_mups: points_per_scale must be in [1, 512]");
-  if (out_cstride < 20 * cfg->n_scales || (out_cstride % 4) != 0) NESTI_FAIL("launch_patches_mups: bad channel stride");
+  const bool x3 = out_dtype == NESTI_BF16X3;
+  if (out_cstride / (x3 ? 3 : 1) < 20 * cfg->n_scales || (out_cstride % (x3 ? 3 * kSplitGroup : 4)) != 0)
+    NESTI_FAIL("launch_patches_mups: bad channel stride");
   if (M <= 0) return 0;
   PatchParams p;
   patch_params_fill(&p, cfg, cloud_dev, N, query_idx_dev, M, r_abs, seed, query_row0, grid_ws_dev);
@@ -482,6 +505,7 @@ int launch_patches_mups(const nesti_config_t* cfg, const float* cloud_dev, int N
   if (out_dtype == NESTI_F32) hipLaunchKernelGGL(patches_mups_kernel<NESTI_F32>, grid, block, 0, stream, p, out, out_cstride, sigma, w);
   else if (out_dtype == NESTI_BF16) hipLaunchKernelGGL(patches_mups_kernel<NESTI_BF16>, grid, block, 0, stream, p, out, out_cstride, sigma, w);
   else if (out_dtype == NESTI_F16) hipLaunchKernelGGL(patches_mups_kernel<NESTI_F16>, grid, block, 0, stream, p, out, out_cstride, sigma, w);
+  else if (x3) hipLaunchKernelGGL(patches_mups_kernel<NESTI_BF16X3>, grid, block, 0, stream, p, out, out_cstride, sigma, w);
   else NESTI_FAIL("launch_patches_mups: unknown out_dtype");
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;

@@ -37,13 +37,39 @@ template <int DT> struct Vec16_16 {
   }
 };
 template <> struct Vec16<NESTI_BF16> : Vec16_16<NESTI_BF16> {};
+// NESTI_BF16X3 activations (common.h): eight logical channels = the hi vector at split_col(col) and the lo vector one
+// 64-element plane further; the value is hi + lo.  Stores emit hi, lo and the second copy of hi.
+__device__ __forceinline__ void load_split8(const unsigned char* base, long long row_elems, int col, float* f) {
+  const unsigned char* s0 = base + (row_elems + split_col(col)) * 2;
+  float h[8], l[8];
+  Vec16<NESTI_BF16>::unpack(*reinterpret_cast<const uint4*>(s0), h);
+  Vec16<NESTI_BF16>::unpack(*reinterpret_cast<const uint4*>(s0 + 2 * kSplitGroup), l);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = h[e] + l[e];
+}
+template <int DT>
+__device__ __forceinline__ void load_vec(const unsigned char* base, long long row_elems, int coff, int cv, int split, float* f) {
+  using V = Vec16<DT>;
+  constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
+  if (DT == NESTI_BF16 && split) { load_split8(base, row_elems, coff + cv * 8, f); return; }
+  V::unpack(*reinterpret_cast<const uint4*>(base + (row_elems + coff) * kEsz + cv * 16), f);
+}
+template <int DT>
+__device__ __forceinline__ void store_vec(unsigned char* base, long long row_elems, int coff, int cv, int split, const float* m) {
+  using V = Vec16<DT>;
+  constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
+  if (DT == NESTI_BF16 && split) {
+    store_act8<Elem<NESTI_BF16>>(base, row_elems, coff + cv * 8, make_float4(m[0], m[1], m[2], m[3]), make_float4(m[4], m[5], m[6], m[7]), 1);
+    return;
+  }
+  *reinterpret_cast<uint4*>(base + (row_elems + coff) * kEsz + cv * 16) = V::pack(m);
+}
 template <> struct Vec16<NESTI_F16> : Vec16_16<NESTI_F16> {};
 
 // tf.nn.max_pool3d 2^3 stride 2 SAME on an even volume (utils/tf_util.py:424-428)
 template <int DT>
 __global__ __launch_bounds__(kThreads) void maxpool2_kernel(const PoolParams p) {
   using V = Vec16<DT>;
-  constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
   int npts = p.npoints;
   if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
   const int log2S = p.log2S, log2V = 3 * log2S;
@@ -65,13 +91,12 @@ __global__ __launch_bounds__(kThreads) void maxpool2_kernel(const PoolParams p) 
     for (int a = 0; a < 8; ++a) {
       const int zz = 2 * z + (a >> 2), yy = 2 * y + ((a >> 1) & 1), xx = 2 * x + (a & 1);
       const long long srow = (pt << log2V) + (((zz << log2S) + yy) << log2S) + xx;
-      const uint4 v = *reinterpret_cast<const uint4*>(in_b + (srow * p.in_cstride + p.in_coff) * kEsz + cv * 16);
       float f[V::N];
-      V::unpack(v, f);
+      load_vec<DT>(in_b, srow * p.in_cstride, p.in_coff, cv, p.split, f);
 #pragma unroll
       for (int e = 0; e < V::N; ++e) m[e] = fmaxf(m[e], f[e]);
     }
-    *reinterpret_cast<uint4*>(out_b + (orow * p.out_cstride + p.out_coff) * kEsz + cv * 16) = V::pack(m);
+    store_vec<DT>(out_b, orow * p.out_cstride, p.out_coff, cv, p.split, m);
   }
 }
 
@@ -81,7 +106,6 @@ __global__ __launch_bounds__(kThreads) void maxpool2_kernel(const PoolParams p) 
 template <int DT>
 __global__ __launch_bounds__(kThreads) void maxpool3s2_kernel(const PoolParams p) {
   using V = Vec16<DT>;
-  constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
   int npts = p.npoints;
   if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
   const int nv = p.C / V::N;
@@ -101,13 +125,12 @@ __global__ __launch_bounds__(kThreads) void maxpool3s2_kernel(const PoolParams p
     for (int a = 0; a < 8; ++a) {
       const int zz = z + (a >> 2), yy = y + ((a >> 1) & 1), xx = x + (a & 1);
       const long long srow = pt * 64 + zz * 16 + yy * 4 + xx;
-      const uint4 v = *reinterpret_cast<const uint4*>(in_b + (srow * p.in_cstride + p.in_coff) * kEsz + cv * 16);
       float f[V::N];
-      V::unpack(v, f);
+      load_vec<DT>(in_b, srow * p.in_cstride, p.in_coff, cv, p.split, f);
 #pragma unroll
       for (int e = 0; e < V::N; ++e) m[e] = fmaxf(m[e], f[e]);
     }
-    *reinterpret_cast<uint4*>(out_b + (orow * p.out_cstride + p.out_coff) * kEsz + cv * 16) = V::pack(m);
+    store_vec<DT>(out_b, orow * p.out_cstride, p.out_coff, cv, p.split, m);
   }
 }
 

@@ -15,7 +15,8 @@ import torch
 from . import _lib
 from .config import ARCH_MULTI, ARCH_SINGLE, DTYPES, NestiConfig
 
-_TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+_TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16,
+             "bf16x3": torch.bfloat16}   # bf16x3: bf16 elements, three planes per 64-channel group (NESTI_BF16X3)
 
 
 def get_3d_grid_gmm(subdivisions=(8, 8, 8), variance=0.0156):
@@ -64,8 +65,9 @@ class NestiNet:
     """The MoE normal estimator on one GPU.
 
     ``weights``: dict name -> float32 ndarray in TF variable layout (see
-    :mod:`.weights`).  ``dtype``: 'bf16' / 'f16' (MFMA 32x32x16, fp32 accumulate) or
-    'f32' (exact-fp32 MFMA; the parity mode)."""
+    :mod:`.weights`).  ``dtype``: 'bf16' / 'f16' (MFMA 32x32x16, fp32 accumulate), 'f32' (exact-fp32 MFMA; the mode
+    tied to the CPU oracle) or 'bf16x3' (activations and weights as bf16 hi + lo pairs, three bf16 MFMA products per
+    multiply: within the reference's 1e-5 cosine tolerance of the f32 mode at a third of the bf16 rate)."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", max_batch=1024):
         self.lib = _lib.load()

@@ -155,6 +155,24 @@ def test_production_dtype_parity_on_10k_queries(big_case, gpu_device, dtype):
     assert rep["argmax_flips"] == rep["flips_margin_flagged"] + rep["flips_outside_margin"]
 
 
+def test_bf16x3_mode_meets_the_north_star_on_10k_queries(big_case, gpu_device):
+    """dtype 'bf16x3' (activations and weights as bf16 hi + lo pairs, three bf16 MFMA products per multiply) against the
+    exact-fp32 mode on the same 10 240 queries: normals within 1e-5 cosine (test_n_est_w_experts.py's outputs to the
+    north star's tolerance) and every arg-max difference inside the near-tie margin, counted."""
+    from nesti_net_amd import parity
+    from nesti_net_amd.pipeline import NormalEstimator
+    cfg, W, pts, q, ref = big_case
+    est = NormalEstimator(cfg, W, dtype="bf16x3", device=gpu_device, batch=4096)
+    out = est.estimate(pts, pidx=q)
+    rep = parity.compare(out, ref)
+    print("bf16x3", rep)
+    assert rep["queries"] == 10240
+    assert rep["flips_outside_margin"] == 0
+    assert rep["argmax_match_rate"] >= 0.999
+    assert rep["one_minus_cos"]["max"] <= 1e-5
+    assert rep["meets_north_star"]
+
+
 def test_fp32_mode_is_batching_invariant_and_self_consistent(big_case, gpu_device):
     """The reference side of every parity figure: the exact-fp32 mode gives the same bits whatever the batch size."""
     from nesti_net_amd import parity
