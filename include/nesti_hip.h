@@ -88,7 +88,9 @@ int nesti_gmm_grid(int n, double variance, float* w, float* mu, float* sigma);
  *   out_dev    [B, R, R, R, out_cstride] of out_dtype; channel 20*s+c holds
  *              scale s, statistic c; channels >= 20*S are written as zero.
  * Rows whose n_eff is 0 (the zero-padded tail of the reference's last batch,
- * test_n_est_w_experts.py:134-140) are written as zeros instead of NaN. */
+ * test_n_est_w_experts.py:134-140) are written as zeros instead of NaN.
+ * out_dtype NESTI_BF16X3: out_cstride is a multiple of 192 bf16 elements and channel c is stored as the planes
+ * hi at 192*(c/64) + c%64, lo 64 elements further, hi again 128 elements further (value = hi + lo). */
 int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev,
                        const int32_t* n_eff_dev, int B, void* out_dev, int out_dtype,
                        int out_cstride, void* stream);
@@ -134,7 +136,7 @@ int nesti_model_describe(const nesti_config_t* cfg, int* n_tensors, nesti_tensor
 
 /* tf.train.Saver().restore equivalent (test_n_est_w_experts.py:98-105): takes the
  * float32 variables, folds the inference-mode batch norm (utils/tf_util.py:491-494)
- * into weights+bias, repacks for the MFMA kernels in `dtype` and uploads.
+ * into weights+bias, repacks for the MFMA kernels in `dtype` (any of the four element types) and uploads.
  * This call allocates device memory owned by the handle and synchronises. */
 int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
                        int n_tensors, int dtype, nesti_model_t** out);
@@ -142,7 +144,8 @@ void nesti_model_destroy(nesti_model_t* m);
 
 /* Scratch size for forward calls of up to max_batch points. */
 size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch);
-int nesti_model_mups_cstride(const nesti_model_t* m); /* channel stride of the internal MuPS tensor */
+int nesti_model_mups_cstride(const nesti_model_t* m); /* channel stride of the internal MuPS tensor, in elements
+                                                       * (NESTI_BF16X3: 3 x the padded channel count, see above) */
 int nesti_model_mups_rows(const nesti_model_t* m);    /* rows per point of the internal MuPS tensor: 512 (8^3 grid)
                                                        * or 64 (3^3 grid: row 16i+4j+k of a 4^3 index space, rows with
                                                        * a coordinate of 3 are zero) */
