@@ -31,11 +31,13 @@ extern "C" {
 #define NESTI_MAX_EXPERTS 8
 #define NESTI_MUPS_CH 20 /* channels per scale: utils/tf_util.py:711-720 */
 
-/* element types for activations / weights.  NESTI_BF16X3 is a MODEL dtype only (nesti_model_create): activations and
- * weights are kept as a bf16 (hi, lo) pair, v ~ hi + lo to 2^-17 relative, and every multiply is the three bf16 MFMA
- * products hi*hi + lo*hi + hi*lo accumulated in fp32 -- the mode that meets the 1e-5 cosine / arg-max tolerance of
- * test_n_est_w_experts.py's outputs at a third of the bf16 rate instead of the fp32 MFMA rate. */
-enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3 };
+/* element types for activations / weights.  NESTI_BF16X3 / NESTI_F16X3 are MODEL dtypes only (nesti_model_create):
+ * activations and weights are kept as a 16-bit (hi, lo) pair, v ~ hi + lo, and every multiply is the three 16-bit MFMA
+ * products hi*hi + lo*hi + hi*lo accumulated in fp32 -- a third of the 16-bit rate instead of the fp32 MFMA rate.
+ * bf16 pairs hold 2^-17 relative; f16 pairs hold max(2^-23 relative, 3e-8 absolute) with the weights of each layer scaled
+ * by a power of two into f16's normal range (undone in the epilogue): the mode that keeps test_n_est_w_experts.py's outputs
+ * within the 1e-5 cosine / arg-max tolerance with two orders of magnitude to spare. */
+enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16X3 = 4 };
 
 /* which graph nesti_model_create builds */
 enum {
@@ -89,7 +91,7 @@ int nesti_gmm_grid(int n, double variance, float* w, float* mu, float* sigma);
  *              scale s, statistic c; channels >= 20*S are written as zero.
  * Rows whose n_eff is 0 (the zero-padded tail of the reference's last batch,
  * test_n_est_w_experts.py:134-140) are written as zeros instead of NaN.
- * out_dtype NESTI_BF16X3: out_cstride is a multiple of 192 bf16 elements and channel c is stored as the planes
+ * out_dtype NESTI_BF16X3 / NESTI_F16X3: out_cstride is a multiple of 192 16-bit elements and channel c is stored as the planes
  * hi at 192*(c/64) + c%64, lo 64 elements further, hi again 128 elements further (value = hi + lo). */
 int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev,
                        const int32_t* n_eff_dev, int B, void* out_dev, int out_dtype,
@@ -145,7 +147,7 @@ void nesti_model_destroy(nesti_model_t* m);
 /* Scratch size for forward calls of up to max_batch points. */
 size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch);
 int nesti_model_mups_cstride(const nesti_model_t* m); /* channel stride of the internal MuPS tensor, in elements
-                                                       * (NESTI_BF16X3: 3 x the padded channel count, see above) */
+                                                       * (NESTI_BF16X3 / NESTI_F16X3: 3 x the padded channel count) */
 int nesti_model_mups_rows(const nesti_model_t* m);    /* rows per point of the internal MuPS tensor: 512 (8^3 grid)
                                                        * or 64 (3^3 grid: row 16i+4j+k of a 4^3 index space, rows with
                                                        * a coordinate of 3 are zero) */

@@ -32,9 +32,9 @@ def build_parser():
     p.add_argument("--batch_size", type=int, default=128, help="Batch size [default: 128]; the library batches internally")
     p.add_argument("--testset", type=str, default="testset_temp.txt", help="test set file name, default testset_temp.txt")
     # extensions (not in the reference)
-    p.add_argument("--dtype", default="f16", choices=["bf16", "f16", "bf16x3", "f32"],
-                   help="MFMA precision mode: f16 (default) / bf16 are the fast modes (parity distributions in DESIGN.md), bf16x3 "
-                        "meets the 1e-5 cosine tolerance at a third of the rate, f32 is the exact-fp32 MFMA mode")
+    p.add_argument("--dtype", default="f16", choices=["bf16", "f16", "f16x3", "bf16x3", "f32"],
+                   help="MFMA precision mode: f16 (default) / bf16 are the fast modes (parity distributions in DESIGN.md), f16x3 "
+                        "(hi + lo pairs) meets the 1e-5 cosine tolerance at a third of the rate, f32 is the exact-fp32 MFMA mode")
     p.add_argument("--synthetic_weights", action="store_true", help="use seeded synthetic weights if model.nstw is absent")
     return p
 

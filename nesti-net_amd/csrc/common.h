@@ -30,8 +30,9 @@ static inline size_t dtype_size(int dt) { return dt == NESTI_F32 ? 4 : 2; }
 // NESTI_BF16X3: the kernels are the bf16 ones; an activation row holds, per group of 64 channels, the three 64-element
 // planes [hi | lo | hi] (192 elements), and the packed weights the matching K order [W_hi ; W_hi ; W_lo], so that the
 // unchanged K loop accumulates hi*W_hi + lo*W_hi + hi*W_lo.  Writers emit the planes (split_col / split_pack2 below).
-static inline int kernel_dtype(int dt) { return dt == NESTI_BF16X3 ? NESTI_BF16 : dt; }
-static inline int act_planes(int dt) { return dt == NESTI_BF16X3 ? 3 : 1; }
+// NESTI_F16X3: the same with f16 pairs and the f16 kernels.
+static inline int kernel_dtype(int dt) { return dt == NESTI_BF16X3 ? NESTI_BF16 : dt == NESTI_F16X3 ? NESTI_F16 : dt; }
+static inline int act_planes(int dt) { return (dt == NESTI_BF16X3 || dt == NESTI_F16X3) ? 3 : 1; }
 constexpr int kSplitGroup = 64;
 __host__ __device__ __forceinline__ int split_col(int col) { return (col >> 6) * (3 * kSplitGroup) + (col & (kSplitGroup - 1)); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -79,13 +80,12 @@ template <> struct Elem<NESTI_F16> {
   }
 };
 
-// (hi, lo) bf16 pair of two values: hi = rne(v), lo = rne(v - hi) (v - hi is exact in fp32)
+// (hi, lo) pair of two values in the 16-bit type E: hi = rne(v), lo = rne(v - hi) (v - hi is exact in fp32)
+template <class E>
 __device__ __forceinline__ void split_pack2(float a, float b, uint32_t& hi, uint32_t& lo) {
-  hi = Elem<NESTI_BF16>::pack2(a, b);
-  lo = Elem<NESTI_BF16>::pack2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+  hi = E::pack2(a, b);
+  lo = E::pack2(a - E::to_f32((uint16_t)(hi & 0xffffu)), b - E::to_f32((uint16_t)(hi >> 16)));
 }
-// the value a (hi, lo) pair stands for
-__device__ __forceinline__ float split_join(uint16_t hi, uint16_t lo) { return bf16_bits_to_f32(hi) + bf16_bits_to_f32(lo); }
 
 // Four / eight consecutive 16-bit channels of one activation row, starting at LOGICAL column col (a multiple of 4 / 8,
 // so a vector never straddles a 64-channel group); row_elems = row * physical channel stride.
@@ -96,8 +96,8 @@ __device__ __forceinline__ void store_act4(unsigned char* base, long long row_el
     return;
   }
   uint32_t h0, l0, h1, l1;
-  split_pack2(a, b, h0, l0);
-  split_pack2(c, d, h1, l1);
+  split_pack2<E>(a, b, h0, l0);
+  split_pack2<E>(c, d, h1, l1);
   unsigned char* d0 = base + (row_elems + split_col(col)) * 2;
   *reinterpret_cast<uint2*>(d0) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(d0 + 2 * kSplitGroup) = make_uint2(l0, l1);
@@ -111,22 +111,25 @@ __device__ __forceinline__ void store_act8(unsigned char* base, long long row_el
     return;
   }
   uint4 h, l;
-  split_pack2(f0.x, f0.y, h.x, l.x);
-  split_pack2(f0.z, f0.w, h.y, l.y);
-  split_pack2(f1.x, f1.y, h.z, l.z);
-  split_pack2(f1.z, f1.w, h.w, l.w);
+  split_pack2<E>(f0.x, f0.y, h.x, l.x);
+  split_pack2<E>(f0.z, f0.w, h.y, l.y);
+  split_pack2<E>(f1.x, f1.y, h.z, l.z);
+  split_pack2<E>(f1.z, f1.w, h.w, l.w);
   unsigned char* d0 = base + (row_elems + split_col(col)) * 2;
   *reinterpret_cast<uint4*>(d0) = h;
   *reinterpret_cast<uint4*>(d0 + 2 * kSplitGroup) = l;
   *reinterpret_cast<uint4*>(d0 + 4 * kSplitGroup) = h;
 }
 
-// NESTI_BF16X3 as a store type (mups.hip): bf16 elements, three planes
+// the pair modes as store types (mups.hip): 16-bit elements, three planes
 template <> struct Elem<NESTI_BF16X3> : Elem<NESTI_BF16> {};
+template <> struct Elem<NESTI_F16X3> : Elem<NESTI_F16> {};
+template <int DT> constexpr bool is_x3 = (DT == NESTI_BF16X3 || DT == NESTI_F16X3);
 
 // host-side conversions used by the weight repacker
 uint16_t host_f32_to_bf16(float f);
 uint16_t host_f32_to_f16(float f);
+float host_f16_to_f32(uint16_t h);
 
 // ---- optional kernel timing (model.hip) -----------------------------------------
 int prof_begin(int category, hipStream_t st);              // returns a token for prof_end (-1: nothing recorded)

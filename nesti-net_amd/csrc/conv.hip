@@ -328,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           int nx = 0;
 #pragma unroll
           for (int c = 0; c < K_; ++c) nx += (x + c - lo >= 0 && x + c - lo < SR_) ? 1 : 0;
-          const float inv = 1.0f / (float)max(1, nz * ny * nx);   // taps inside the volume (utils/tf_util.py:450-454); 0 only on dead rows
+          const float inv = p.acc_scale / (float)max(1, nz * ny * nx);   // taps inside the volume (utils/tf_util.py:450-454); 0 only on dead rows
           const float o[4] = {fmaxf(sum[x].x * inv + bb.x, act_floor), fmaxf(sum[x].y * inv + bb.y, act_floor),
                               fmaxf(sum[x].z * inv + bb.z, act_floor), fmaxf(sum[x].w * inv + bb.w, act_floor)};
           const long long gr = r0 + row0 + x;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = tile_row(remap, log2S, wave, mi, (r & 3) + 8 * (r >> 2) + 4 * khalf);
-            *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = fmaxf(acc[mi][ni][r] + bv, act_floor);
+            *reinterpret_cast<float*>(smem + row * kPoolStride + col * 4) = fmaxf(fmaf(acc[mi][ni][r], p.acc_scale, bv), act_floor);
           }
         }
       __syncthreads();
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-          *reinterpret_cast<float*>(scratch + row * kPoolStride + col * 4) = fmaxf(acc[mi][ni][r] + bv, act_floor);
+          *reinterpret_cast<float*>(scratch + row * kPoolStride + col * 4) = fmaxf(fmaf(acc[mi][ni][r], p.acc_scale, bv), act_floor);
         }
       }
       if (out_esz == 4) {

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
       for (int r = 0; r < 16; ++r) {
         const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;      // MFMA row = 8 pt + x
         const int row = ((((m >> 3) * 4 + jj) * 8 + y) << 3) + (m & 7);
-        *reinterpret_cast<float*>(smem + row * kEpiStride + l31 * 4) = fmaxf(acc[j][r] + bv, act_floor);
+        *reinterpret_cast<float*>(smem + row * kEpiStride + l31 * 4) = fmaxf(fmaf(acc[j][r], p.acc_scale, bv), act_floor);
       }
     }
     __syncthreads();

@@ -45,9 +45,11 @@ struct ConvParams {
   // 8 points (4^3), dealt to the 4 SIMDs as a Latin square so that the tiles a padding tap skips are spread evenly
   // over the matrix pipes (conv.hip: tile_row).  0 = tile t holds rows [32t, 32t+32).
   int remap;
-  // NESTI_BF16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (three planes per
+  // NESTI_BF16X3 / NESTI_F16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (three planes per
   // 64-channel group); out_coff / out_coff2 stay logical and every 16-bit store goes through split_col + three planes.
   int split;
+  float acc_scale;     // the accumulators are multiplied by this before the bias (1, or 2^-s when the layer's packed weights
+                       // carry a 2^s scale: NESTI_F16X3 keeps the weight pairs in f16's normal range that way)
   int8_t tap[kMaxTaps][4];   // dz, dy, dx, -
 };
 
@@ -64,7 +66,7 @@ struct PoolParams {
   int in_cstride, in_coff, out_cstride, out_coff;
   int C;               // channels to process (multiple of 8)
   int log2S;           // input S
-  int split;           // NESTI_BF16X3: cstrides physical, in_coff / out_coff / C logical (split_col), values = hi + lo
+  int split;           // pair modes: cstrides physical, in_coff / out_coff / C logical (split_col), values = hi + lo
 };
 int launch_maxpool2(const PoolParams& p, int dtype, hipStream_t stream);
 // tf.nn.max_pool3d [3,3,3] stride 2 SAME on a 3^3 volume (models/experts_n_est.py:238): input rows in the 4^3-embedded

@@ -92,6 +92,12 @@ uint16_t host_f32_to_f16(float f) {
   return b;
 }
 
+float host_f16_to_f32(uint16_t b) {
+  _Float16 h;
+  memcpy(&h, &b, 2);
+  return (float)h;
+}
+
 namespace {
 
 constexpr int kPad = 64;   // channel segments are zero-padded to multiples of this
@@ -402,6 +408,7 @@ struct PackedLayer {
   float* bias = nullptr;
   int TN = 64, n_tiles = 0, split_tile = 0, n_chunks = 0, n_taps = 0;
   int kind = 0;              // 0: conv_igemm_kernel (conv.hip), 1: conv8_kernel (conv8.hip: 4 points per workgroup)
+  float acc_scale = 1.0f;    // 2^-s when the packed weights carry a 2^s scale (NESTI_F16X3)
   int8_t tap[kMaxTaps][4];
 };
 
@@ -513,7 +520,7 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
         ++pl->n_taps;
       }
   const size_t esz = dtype_size(dtype);
-  // NESTI_BF16X3 (common.h): K runs over the physical input row -- per 64-channel group the planes [hi | lo | hi] -- and
+  // NESTI_BF16X3 / NESTI_F16X3 (common.h): K runs over the physical input row -- per 64-channel group the planes [hi | lo | hi] -- and
   // the weights follow it as [W_hi ; W_hi ; W_lo], so the unchanged K loop accumulates hi*W_hi + lo*W_hi + hi*W_lo
   const int planes = act_planes(dtype);
   const int K_phys = d.Cin_p * planes;
@@ -527,6 +534,28 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
   pl->n_chunks = K_phys / KC;
   if (K_phys % KC || d.Cin_p % kSplitGroup) NESTI_FAIL("internal: Cin_p not a multiple of the K chunk");
   if (n_parts == 2 && pl->n_taps != 1) NESTI_FAIL("internal: fused layers must be 1x1x1");
+  // NESTI_F16X3: one power-of-two scale per layer brings the largest folded weight to ~2^14, so that the lo halves of the
+  // weight pairs (2^-12 of a weight) are normal f16 numbers; the epilogue multiplies the accumulators by 2^-s (exact)
+  float wmul = 1.0f;
+  pl->acc_scale = 1.0f;
+  if (dtype == NESTI_F16X3) {
+    float wmax = 0.f;
+    for (int part = 0; part < n_parts; ++part) {
+      const Folded& f = parts[part];
+      for (size_t t = 0; t < tap_widx.size(); ++t) {
+        const float* wt = f.w + (size_t)tap_widx[t] * d.cin * d.cout;
+        for (int c = 0; c < d.cin; ++c)
+          for (int n = 0; n < d.cout; ++n) wmax = std::max(wmax, fabsf(wt[(size_t)c * d.cout + n] * f.scale[n]));
+      }
+    }
+    int e = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) {
+      (void)frexpf(wmax, &e);                  // wmax = m 2^e, m in [0.5, 1)
+      e = std::min(24, std::max(-8, 14 - e));  // wmax 2^s in [2^13, 2^14)
+    }
+    wmul = ldexpf(1.0f, e);
+    pl->acc_scale = ldexpf(1.0f, -e);
+  }
   std::vector<int> inv(d.Cin_p, -1);
   for (int c = 0; c < d.cin; ++c) inv[d.in_pos[c]] = c;
   const size_t tile_bytes = (size_t)pl->TN * row_bytes;
@@ -551,19 +580,19 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
           for (int nl = 0; nl < pl->TN; ++nl) {
             const int n = n_base + nl;
             if (n >= d.cout) break;
-            const float v = wrow[n] * f.scale[n];
+            const float v = wrow[n] * f.scale[n] * wmul;
             // the kernels' LDS image: row nl, 16-B slot XOR-swizzled (conv8_kernel: 64-B rows, key (row >> 2) & 3)
             unsigned char* dst = pl->kind == 1
                 ? tile + (size_t)nl * 64 + ((slot ^ ((nl >> 2) & 3)) << 4) + within * esz
                 : tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
             if (dtype == NESTI_F32) memcpy(dst, &v, 4);
-            else if (dtype == NESTI_BF16X3) {
-              uint16_t h = host_f32_to_bf16(v);
+            else if (planes == 3) {
+              const bool b16 = dtype == NESTI_BF16X3;
+              uint16_t h = b16 ? host_f32_to_bf16(v) : host_f32_to_f16(v);
               if (plane == 2) {                              // W_lo = rne(W - W_hi)
-                const uint32_t hb = (uint32_t)h << 16;
                 float hf;
-                memcpy(&hf, &hb, 4);
-                h = host_f32_to_bf16(v - hf);
+                if (b16) { const uint32_t hb = (uint32_t)h << 16; memcpy(&hf, &hb, 4); } else hf = host_f16_to_f32(h);
+                h = b16 ? host_f32_to_bf16(v - hf) : host_f32_to_f16(v - hf);
               }
               memcpy(dst, &h, 2);
             } else {
@@ -687,14 +716,14 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf]; p.wpk = pl.wpk; p.bias = pl.bias;
       p.npoints_ptr = rc.npoints_ptr; p.point_index = ext_in ? rc.point_index : nullptr;
       p.npoints = rc.NB;
-      // NESTI_BF16X3: strides and the input offset are physical (a 64-aligned logical offset x 3), output column
+      // pair modes: strides and the input offset are physical (a 64-aligned logical offset x 3), output column
       // offsets stay logical (kernels.h: ConvParams::split); an fp32 output buffer is an ordinary one
       const int planes = act_planes(dtype);
       p.split = planes > 1 ? 1 : 0;
       p.in_cstride = (op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C) * planes; p.in_coff = op.in_coff * planes;
       p.out_cstride = T.bufs[op.out_buf].C * (op.out_f32 ? 1 : planes); p.out_coff = op.out_coff;
       p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S; p.s_real = d.s_real;
-      p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0;
+      p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0; p.acc_scale = pl.acc_scale;
       const long long rows = (long long)rc.NB << (3 * d.log2S);
       p.m_tiles = pl.kind == 1 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
@@ -732,7 +761,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
   return 0;
 }
 
-// channel stride of the MuPS rows the towers read, in elements (NESTI_BF16X3: three planes per 64-channel group)
+// channel stride of the MuPS rows the towers read, in elements (pair modes: three planes per 64-channel group)
 int mups_stride(const nesti_model* m) { return m->graph.mups_cstride * act_planes(m->dtype); }
 
 size_t max_tower_bytes(const nesti_model* m, int NB) {
@@ -870,7 +899,7 @@ int nesti_model_describe(const nesti_config_t* cfg, int* n_tensors, nesti_tensor
 int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors, int n_tensors, int dtype,
                        nesti_model_t** out) {
   if (!cfg || !tensors || !out) NESTI_FAIL("nesti_model_create: null argument");
-  if (dtype != NESTI_F32 && dtype != NESTI_BF16 && dtype != NESTI_F16 && dtype != NESTI_BF16X3) NESTI_FAIL("nesti_model_create: bad dtype");
+  if (dtype != NESTI_F32 && dtype != NESTI_BF16 && dtype != NESTI_F16 && dtype != NESTI_BF16X3 && dtype != NESTI_F16X3) NESTI_FAIL("nesti_model_create: bad dtype");
   std::unique_ptr<nesti_model> m(new nesti_model());
   m->dtype = dtype;
   if (build_graph(cfg, &m->graph)) return 1;

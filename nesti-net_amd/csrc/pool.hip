@@ -37,34 +37,39 @@ template <int DT> struct Vec16_16 {
   }
 };
 template <> struct Vec16<NESTI_BF16> : Vec16_16<NESTI_BF16> {};
-// NESTI_BF16X3 activations (common.h): eight logical channels = the hi vector at split_col(col) and the lo vector one
-// 64-element plane further; the value is hi + lo.  Stores emit hi, lo and the second copy of hi.
-__device__ __forceinline__ void load_split8(const unsigned char* base, long long row_elems, int col, float* f) {
-  const unsigned char* s0 = base + (row_elems + split_col(col)) * 2;
-  float h[8], l[8];
-  Vec16<NESTI_BF16>::unpack(*reinterpret_cast<const uint4*>(s0), h);
-  Vec16<NESTI_BF16>::unpack(*reinterpret_cast<const uint4*>(s0 + 2 * kSplitGroup), l);
-#pragma unroll
-  for (int e = 0; e < 8; ++e) f[e] = h[e] + l[e];
-}
+template <> struct Vec16<NESTI_F16> : Vec16_16<NESTI_F16> {};
+
+// Pair-mode activations (NESTI_BF16X3 / NESTI_F16X3, common.h): eight logical channels = the hi vector at split_col(col)
+// and the lo vector one 64-element plane further; the value is hi + lo.  Stores emit hi, lo and the second copy of hi.
 template <int DT>
 __device__ __forceinline__ void load_vec(const unsigned char* base, long long row_elems, int coff, int cv, int split, float* f) {
   using V = Vec16<DT>;
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
-  if (DT == NESTI_BF16 && split) { load_split8(base, row_elems, coff + cv * 8, f); return; }
+  if constexpr (DT != NESTI_F32) {
+    if (split) {
+      const unsigned char* s0 = base + (row_elems + split_col(coff + cv * 8)) * 2;
+      float h[8], l[8];
+      V::unpack(*reinterpret_cast<const uint4*>(s0), h);
+      V::unpack(*reinterpret_cast<const uint4*>(s0 + 2 * kSplitGroup), l);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = h[e] + l[e];
+      return;
+    }
+  }
   V::unpack(*reinterpret_cast<const uint4*>(base + (row_elems + coff) * kEsz + cv * 16), f);
 }
 template <int DT>
 __device__ __forceinline__ void store_vec(unsigned char* base, long long row_elems, int coff, int cv, int split, const float* m) {
   using V = Vec16<DT>;
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
-  if (DT == NESTI_BF16 && split) {
-    store_act8<Elem<NESTI_BF16>>(base, row_elems, coff + cv * 8, make_float4(m[0], m[1], m[2], m[3]), make_float4(m[4], m[5], m[6], m[7]), 1);
-    return;
+  if constexpr (DT != NESTI_F32) {
+    if (split) {
+      store_act8<Elem<DT>>(base, row_elems, coff + cv * 8, make_float4(m[0], m[1], m[2], m[3]), make_float4(m[4], m[5], m[6], m[7]), 1);
+      return;
+    }
   }
   *reinterpret_cast<uint4*>(base + (row_elems + coff) * kEsz + cv * 16) = V::pack(m);
 }
-template <> struct Vec16<NESTI_F16> : Vec16_16<NESTI_F16> {};
 
 // tf.nn.max_pool3d 2^3 stride 2 SAME on an even volume (utils/tf_util.py:424-428)
 template <int DT>

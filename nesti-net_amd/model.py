@@ -16,7 +16,7 @@ from . import _lib
 from .config import ARCH_MULTI, ARCH_SINGLE, DTYPES, NestiConfig
 
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16,
-             "bf16x3": torch.bfloat16}   # bf16x3: bf16 elements, three planes per 64-channel group (NESTI_BF16X3)
+             "bf16x3": torch.bfloat16, "f16x3": torch.float16}   # pair modes: 16-bit elements, three planes per 64-channel group
 
 
 def get_3d_grid_gmm(subdivisions=(8, 8, 8), variance=0.0156):
@@ -66,8 +66,9 @@ class NestiNet:
 
     ``weights``: dict name -> float32 ndarray in TF variable layout (see
     :mod:`.weights`).  ``dtype``: 'bf16' / 'f16' (MFMA 32x32x16, fp32 accumulate), 'f32' (exact-fp32 MFMA; the mode
-    tied to the CPU oracle) or 'bf16x3' (activations and weights as bf16 hi + lo pairs, three bf16 MFMA products per
-    multiply: within the reference's 1e-5 cosine tolerance of the f32 mode at a third of the bf16 rate)."""
+    tied to the CPU oracle) or the pair modes 'f16x3' / 'bf16x3' (activations and weights as 16-bit hi + lo pairs, three
+    MFMA products per multiply, a third of the 16-bit rate: f16x3 stays two orders of magnitude inside the reference's 1e-5
+    cosine tolerance of the f32 mode, bf16x3 is at its edge)."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", max_batch=1024):
         self.lib = _lib.load()

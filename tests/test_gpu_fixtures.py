@@ -129,7 +129,7 @@ def big_case(gpu_device):
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_production_dtype_parity_on_10k_queries(big_case, gpu_device, dtype):
     """The numbers bench.py prints under "parity", asserted on 10 240 queries with the data-matched synthetic weights.
-    Neither plain 16-bit mode meets the north star's tolerance (bit-exact arg-max, 1e-5 cosine) -- the bf16x3 mode (next
+    Neither plain 16-bit mode meets the north star's tolerance (bit-exact arg-max, 1e-5 cosine) -- the pair modes (next
     test) and the exact-fp32 MFMA mode do, and the latter is what the oracle tests hold to it.  What is asserted here is each dtype's measured
     distribution with headroom: f16 (the default) keeps > 98.5 % of the arg-maxes with a median 1 - cos of a few 1e-6,
     bf16 (3 % faster) > 90 % with a median of a few 1e-4."""
@@ -155,21 +155,24 @@ def test_production_dtype_parity_on_10k_queries(big_case, gpu_device, dtype):
     assert rep["argmax_flips"] == rep["flips_margin_flagged"] + rep["flips_outside_margin"]
 
 
-def test_bf16x3_mode_meets_the_north_star_on_10k_queries(big_case, gpu_device):
-    """dtype 'bf16x3' (activations and weights as bf16 hi + lo pairs, three bf16 MFMA products per multiply) against the
-    exact-fp32 mode on the same 10 240 queries: normals within 1e-5 cosine (test_n_est_w_experts.py's outputs to the
-    north star's tolerance) and every arg-max difference inside the near-tie margin, counted."""
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x3"])
+def test_pair_modes_meet_the_north_star_on_10k_queries(big_case, gpu_device, mode):
+    """dtype 'f16x3' / 'bf16x3' (activations and weights as 16-bit hi + lo pairs, three MFMA products per multiply)
+    against the exact-fp32 mode on the same 10 240 queries: normals within 1e-5 cosine (test_n_est_w_experts.py's outputs
+    to the north star's tolerance) and every arg-max difference inside the near-tie margin, counted.  f16x3 keeps two
+    orders of magnitude of headroom; bf16x3 is within the tolerance here but at its edge on other clouds
+    (scripts/pair_mode_sweep.py)."""
     from nesti_net_amd import parity
     from nesti_net_amd.pipeline import NormalEstimator
     cfg, W, pts, q, ref = big_case
-    est = NormalEstimator(cfg, W, dtype="bf16x3", device=gpu_device, batch=4096)
+    est = NormalEstimator(cfg, W, dtype=mode, device=gpu_device, batch=4096)
     out = est.estimate(pts, pidx=q)
     rep = parity.compare(out, ref)
-    print("bf16x3", rep)
+    print(mode, rep)
     assert rep["queries"] == 10240
     assert rep["flips_outside_margin"] == 0
     assert rep["argmax_match_rate"] >= 0.999
-    assert rep["one_minus_cos"]["max"] <= 1e-5
+    assert rep["one_minus_cos"]["max"] <= (1e-7 if mode == "f16x3" else 1e-5)
     assert rep["meets_north_star"]
 
 

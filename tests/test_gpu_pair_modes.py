@@ -1,12 +1,14 @@
-"""dtype 'bf16x3' (NESTI_BF16X3): activations and weights as bf16 (hi, lo) pairs, three bf16 MFMA products per
-multiply through the same kernels as bf16 (planes [hi | lo | hi] per 64-channel group, weights [W_hi ; W_hi ; W_lo]).
+"""The pair modes 'f16x3' / 'bf16x3' (NESTI_F16X3 / NESTI_BF16X3): activations and weights as 16-bit (hi, lo) pairs,
+three MFMA products per multiply through the same kernels as f16 / bf16 (planes [hi | lo | hi] per 64-channel group,
+weights [W_hi ; W_hi ; W_lo]; f16x3 also scales each layer's weights by a power of two into f16's normal range).
 
-It is the mode that holds test_n_est_w_experts.py's outputs to the north star's tolerance (arg-max exact or
-margin-flagged, normals within 1e-5 cosine) without the fp32 MFMA rate.  Checked here against the fp64 CPU oracle on
-golden patches, and against the exact-fp32 mode on every graph the builder makes (each exercises a different part of
-the plane layout: flattened FC inputs, the 3^3 grid's embedded rows and max-pool, two 64-channel groups of MuPS
-channels, first-block widths that are not multiples of 64).  The 10 240-query and 100 000-query figures are in
-tests/test_gpu_fixtures.py and bench.py."""
+f16x3 is the mode that holds test_n_est_w_experts.py's outputs to the north star's tolerance (arg-max exact or
+margin-flagged, normals within 1e-5 cosine) without the fp32 MFMA rate; bf16x3 (2^-17 operands) sits at the edge of
+it.  Checked here against the fp64 CPU oracle on golden patches, and against the exact-fp32 mode on every graph the
+builder makes (each exercises a different part of the plane layout: flattened FC inputs, the 3^3 grid's embedded rows
+and max-pool, two 64-channel groups of MuPS channels, first-block widths that are not multiples of 64).  The
+10 240-query and 100 000-query figures are in tests/test_gpu_fixtures.py and bench.py; other clouds in
+scripts/pair_mode_sweep.py."""
 import numpy as np
 import pytest
 import torch
@@ -16,6 +18,8 @@ from conftest import golden_patch_files, load_golden_patches
 pytestmark = pytest.mark.gpu
 
 COS_TOL = 1e-5
+MODES = ["f16x3", "bf16x3"]
+TORCH_DT = {"f16x3": torch.float16, "bf16x3": torch.bfloat16}
 
 
 def _cos(a, b):
@@ -28,7 +32,8 @@ def _golden(name, rows):
     return g["points"][:rows], g["n_eff"][:rows]
 
 
-def test_bf16x3_matches_the_fp64_oracle_on_golden_patches(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_pair_mode_matches_the_fp64_oracle_on_golden_patches(mode, gpu_device):
     from nesti_net_amd import weights
     from nesti_net_amd.config import NestiConfig
     from nesti_net_amd.model import NestiNet
@@ -41,11 +46,11 @@ def test_bf16x3_matches_the_fp64_oracle_on_golden_patches(gpu_device):
     mups_o = mups_ref.mups_assemble(pts, n_eff, 3)
     full = net_ref.moe_forward(mups_o[:6], W, dtype=torch.float64, top1_only=False)
     top1 = net_ref.moe_forward(mups_o, W, dtype=torch.float64, top1_only=True)
-    net = NestiNet(cfg, W, dtype="bf16x3", device=gpu_device, max_batch=16)
+    net = NestiNet(cfg, W, dtype=mode, device=gpu_device, max_batch=16)
     p, n = torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device)
-    # the MuPS rows the towers read: three planes per 64-channel group, hi + lo = the fp32 value to 2^-17
+    # the MuPS rows the towers read: three planes per 64-channel group, hi + lo = the fp32 value to 2^-17 (bf16 pairs)
     mups = net.mups(p, n)
-    assert mups.shape == (16, 8, 8, 8, 192) and mups.dtype == torch.bfloat16
+    assert mups.shape == (16, 8, 8, 8, 192) and mups.dtype == TORCH_DT[mode]
     m = mups.float().cpu().numpy()
     assert np.array_equal(m[..., 0:64], m[..., 128:192])
     assert np.abs(m[..., 0:60] + m[..., 64:124] - mups_o).max() < 2e-5
@@ -59,10 +64,12 @@ def test_bf16x3_matches_the_fp64_oracle_on_golden_patches(gpu_device):
     c = _cos(normals.cpu().numpy()[agree], top1["normals"].numpy()[agree])
     n_est = net.experts(mups[:6], None).cpu().numpy()
     ca = _cos(n_est, full["n_est"].numpy())
-    print("bf16x3 vs oracle: prob err", pe, "agree", agree.mean(), "1-cos max", (1 - c).max(), "all experts", (1 - ca).max())
-    assert pe < 1e-3                                   # 2^-17 operands on O(10) logits (the fp32 mode: 1e-4)
-    assert np.all(agree | (margin < 2e-3))
+    print(mode, "vs oracle: prob err", pe, "agree", agree.mean(), "1-cos max", (1 - c).max(), "all experts", (1 - ca).max())
+    assert pe < (1e-3 if mode == "bf16x3" else 1e-4)  # 2^-17 operands on O(10) logits; f16 pairs: like the fp32 mode
+    assert np.all(agree | (margin < (2e-3 if mode == "bf16x3" else 2e-4)))
     assert np.all(1 - c < COS_TOL) and np.all(1 - ca < COS_TOL)
+    if mode == "f16x3":
+        assert (1 - c).max() < 1e-7 and (1 - ca).max() < 1e-7
 
 
 def _cases():
@@ -74,8 +81,9 @@ def _cases():
     yield "four_experts_mixed_scales", NestiConfig(n_experts=4, expert_dict={0: [0], 1: [1, 2], 2: [2], 3: [0, 1, 2]}), "ellipsoid20k", None
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["experts_3cubed_grid", "ss_norm_est", "ms_norm_est", "ms_sw_n_est", "four_experts_mixed_scales"])
-def test_bf16x3_agrees_with_the_fp32_mode_on_every_graph(name, gpu_device):
+def test_pair_mode_agrees_with_the_fp32_mode_on_every_graph(name, mode, gpu_device):
     from nesti_net_amd import weights
     from nesti_net_amd.model import NestiNet
     _, cfg, golden, scales = [c for c in _cases() if c[0] == name][0]
@@ -89,7 +97,7 @@ def test_bf16x3_agrees_with_the_fp32_mode_on_every_graph(name, gpu_device):
         pts, n_eff = pts[:, :512], n_eff[:, :1]
     p, n = torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device)
     outs = {}
-    for dt in ("f32", "bf16x3"):
+    for dt in ("f32", mode):
         net = NestiNet(cfg, W, dtype=dt, device=gpu_device, max_batch=B)
         normals, expert, probs = net(p, n)
         mups = net.mups(p, n)
@@ -98,9 +106,9 @@ def test_bf16x3_agrees_with_the_fp32_mode_on_every_graph(name, gpu_device):
         outs[dt] = (normals.cpu().numpy(), None if expert is None else expert.cpu().numpy(),
                     None if probs is None else probs.cpu().numpy(), every.cpu().numpy())
         del net
-    (n_r, e_r, p_r, a_r), (n_t, e_t, p_t, a_t) = outs["f32"], outs["bf16x3"]
+    (n_r, e_r, p_r, a_r), (n_t, e_t, p_t, a_t) = outs["f32"], outs[mode]
     worst = (1 - _cos(a_t, a_r)).max()
-    print(name, "all towers 1-cos max", worst, "prob err", None if p_r is None else np.abs(p_t - p_r).max())
+    print(name, mode, "all towers 1-cos max", worst, "prob err", None if p_r is None else np.abs(p_t - p_r).max())
     assert worst < COS_TOL
     if p_r is not None:
         assert np.abs(p_t - p_r).max() < 3e-4
@@ -109,7 +117,8 @@ def test_bf16x3_agrees_with_the_fp32_mode_on_every_graph(name, gpu_device):
     assert np.all(1 - _cos(n_t[same], n_r[same]) < COS_TOL)
 
 
-def test_bf16x3_limits_two_channel_groups_and_ragged_batches(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_pair_mode_limits_two_channel_groups_and_ragged_batches(mode, gpu_device):
     """NESTI_MAX_SCALES = 4: 80 MuPS channels = two 64-channel groups of planes; a batch that is not a multiple of the
     four points conv8_kernel handles per workgroup; rows with n_eff = 0 are skipped, not computed."""
     from nesti_net_amd import weights
@@ -127,7 +136,7 @@ def test_bf16x3_limits_two_channel_groups_and_ragged_batches(gpu_device):
             pts[b, 128 * s + n_eff[b, s]:128 * (s + 1)] = 0
     p, n = torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device)
     ref = NestiNet(cfg, W, dtype="f32", device=gpu_device, max_batch=B)
-    net = NestiNet(cfg, W, dtype="bf16x3", device=gpu_device, max_batch=B)
+    net = NestiNet(cfg, W, dtype=mode, device=gpu_device, max_batch=B)
     assert net.mups_cstride == 3 * 128
     m = net.mups(p, n).float().cpu().numpy()
     m32 = ref.mups(p, n).cpu().numpy()
