@@ -1,4 +1,4 @@
-"""The whole hot path in the exact-fp32 MFMA mode against the CPU oracle on every golden fixture's cloud
+"""The whole hot path in the exact-fp32 MFMA mode (and the f16x3 pair mode) against the CPU oracle on every golden fixture's cloud
 (no-noise / PCPNet noise levels / gradient and striped density / small P / single scale), on >= 256 queries drawn
 ACROSS each cloud (strided) plus the fixture's own reference-captured queries, with a calibrated gate so that the
 routed top-1 path exercises every expert -- and the production dtypes against the fp32 mode on >= 10k queries.
@@ -86,8 +86,10 @@ def test_f32_path_matches_oracle_across_fixture_cloud(name, gpu_device):
     if cfg.arch == ARCH_SINGLE:
         ref = torch.cat([net_ref.single_forward(mups_o[i:i + 64], W, dtype=torch.float64) for i in range(0, len(q), 64)]).numpy()
         c = _cos(normals.cpu().numpy(), ref)
-        print(name, "ss_norm_est 1-cos max", (1 - c).max())
-        assert np.all(1 - c < 1e-5)
+        n3, _, _ = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=len(q))(p_d, n_d)
+        c3 = _cos(n3.cpu().numpy(), ref)
+        print(name, "ss_norm_est 1-cos max", (1 - c).max(), "f16x3", (1 - c3).max())
+        assert np.all(1 - c < 1e-5) and np.all(1 - c3 < 1e-5)
         return
     ref = _oracle_moe(mups_o, W, cfg)
     ex = expert.cpu().numpy()
@@ -102,6 +104,17 @@ def test_f32_path_matches_oracle_across_fixture_cloud(name, gpu_device):
     assert perr < 1e-4                                 # the calibrated gate's last layer amplifies logit differences
     assert np.all(agree | (margin < 2e-4))            # arg-max exact unless the fp64 oracle itself is tied to 2e-4
     assert np.all(1 - c < 1e-5)
+    # ---- the same rows in the f16x3 pair mode (the north-star mode of the bench) against the same oracle results ----
+    del net
+    n3, e3, p3 = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=len(q))(p_d, n_d)
+    torch.cuda.synchronize()
+    agree3 = e3.cpu().numpy() == ref["expert"]
+    perr3 = np.abs(p3.cpu().numpy() - ref["probs"]).max()
+    c3 = _cos(n3.cpu().numpy()[agree3], ref["normals"][agree3])
+    print(name, "f16x3: prob err", perr3, "flips", int((~agree3).sum()), "1-cos max", (1 - c3).max())
+    assert perr3 < 2e-4
+    assert np.all(agree3 | (margin < 4e-4))
+    assert np.all(1 - c3 < 1e-5)
 
 
 @pytest.fixture(scope="module")
