@@ -26,10 +26,10 @@
 // per-lane base (x + dx shift, swizzle) plus a wave-uniform base plus a compile-time j * 2048.
 //
 // Pipeline.  Weight tiles of one (dz, dy) row of taps (k tiles, 2 KiB each) stream L2 -> LDS by LDS-DMA two rows
-// ahead into 3 slots, one barrier per row.  Within a wave, the A fragments of tap t + 1 are read into the registers
+// ahead into 3 slots, one barrier per row (k = 5); pairs of rows one pair ahead into 2 slots, one barrier per pair (k = 3).  Within a wave, the A fragments of tap t + 1 are read into the registers
 // tile j's MFMAs of tap t have just consumed (a full tap of lookahead, 64 VGPRs), one s_waitcnt lgkmcnt(0) per tap.
 //
-// LDS: [0, 32 KiB) weight slots (3 x k x 2 KiB), [32, 160 KiB) the input chunk; rows are 64 B with the 16-B slot
+// LDS: [0, 32 KiB) weight slots (3 x 10 KiB for k = 5, 2 x 12 KiB for k = 3), [32, 160 KiB) the input chunk; rows are 64 B with the 16-B slot
 // XOR-swizzled by the point index (input) / (row >> 2) & 3 (weights), applied on the DMA source address, which makes
 // every ds_read_b128 lane group conflict-free.  The epilogue reuses the whole 160 KiB as an fp32 staging tile.
 //
@@ -67,9 +67,17 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
   constexpr int LO = (K - 1) / 2;
-  constexpr int kSlot = K * kTileBytes;      // weight tiles of one (dz, dy) row of taps
-  constexpr int NG = K * K;                  // rows of taps per chunk
-  static_assert(3 * kSlot <= kAOff, "weight slots must fit below the input chunk");
+  constexpr int NG = K * K;                  // (dz, dy) rows of taps per chunk
+  // Weight slots: a slot holds R rows of taps and is recycled behind a workgroup barrier.  k = 5: one row (10 KiB) per
+  // slot, three slots, streamed two rows ahead.  k = 3: a row is only 3 taps, so two rows (12 KiB) share a slot and a
+  // barrier -- 5 barriers per chunk instead of 9 -- with two slots, streamed one pair ahead.
+  constexpr int R = (K == 3) ? 2 : 1;
+  constexpr int NS = (K == 3) ? 2 : 3;
+  constexpr int AHEAD = NS - 1;
+  constexpr int kSlot = R * K * kTileBytes;
+  constexpr int NSR = (NG + R - 1) / R;      // slot fills per chunk
+  static_assert(NS * kSlot <= kAOff, "weight slots must fit below the input chunk");
+  static_assert((NG - K) % R == 0 && (NG - 1) % R == 0, "the early staging points must follow a barrier");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,10 +123,14 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
         if (a_ok[h]) glds16(src + a_voff[h], lds0 + kAOff + (wave * 8 + j) * kTileBytes + h * 1024);
     }
   };
-  auto stage_b = [&](int c, int g, int slot) __attribute__((always_inline)) {
-    const unsigned char* src = w_tile + ((size_t)c * (K * K * K) + (size_t)g * K) * kTileBytes;
-    for (int pid = wave; pid < 2 * K; pid += 8)
+  auto stage_b = [&](int c, int sr, int slot) __attribute__((always_inline)) {   // rows sr * R .. of chunk c
+    const unsigned char* src = w_tile + ((size_t)c * (K * K * K) + (size_t)sr * R * K) * kTileBytes;
+    const int pieces = 2 * K * min(R, NG - sr * R);
+    for (int pid = wave; pid < pieces; pid += 8)
       glds16(src + pid * 1024 + lane * 16, lds0 + slot * kSlot + pid * 1024);
+  };
+  auto b_slot = [&](int g) __attribute__((always_inline)) -> unsigned {   // LDS byte offset of row g's weight tiles
+    return (unsigned)(((g / R) % NS) * kSlot + (g % R) * K * kTileBytes);
   };
 
   // ---- per-lane fragment coordinates ---------------------------------------------------------------------------
@@ -180,8 +192,8 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
   for (int c = 0; c < p.n_chunks; ++c) {
     __syncthreads();                       // every wave is done with the previous chunk
     stage_a(c, c == 0 ? 0xffu : pre_none);
-    stage_b(c, 0, 0);
-    stage_b(c, 1, 1);
+#pragma unroll
+    for (int sr = 0; sr < AHEAD; ++sr) stage_b(c, sr, sr);
     wait_vm0();
     __syncthreads();
     // prologue: fragments of tap 0 (row 0, dx = -LO)
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
         }
     }
     for (int g = 0; g < NG; ++g) {
-      if (g + 2 < NG) stage_b(c, g + 2, (g + 2) % 3);
+      if (g % R == 0 && g / R + AHEAD < NSR) stage_b(c, g / R + AHEAD, (g / R + AHEAD) % NS);
       if (c + 1 < p.n_chunks) {            // early staging of the next chunk into slots this chunk no longer reads
         if (g == NG - K) stage_a(c + 1, pre_slab);
         if (g == NG - 1) stage_a(c + 1, pre_row);
@@ -209,8 +221,8 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
       const unsigned mask_n = (g + 1 < NG) ? row_mask(g + 1) : 0u;
       const int base_g = row_base(g);
       const int base_n = (g + 1 < NG) ? row_base(g + 1) : 0;
-      const unsigned bslot_g = (unsigned)((g % 3) * kSlot);
-      const unsigned bslot_n = (unsigned)(((g + 1) % 3) * kSlot);
+      const unsigned bslot_g = b_slot(g);
+      const unsigned bslot_n = b_slot(g + 1);
 #pragma unroll
       for (int u = 0; u < K; ++u) {
         const bool last_u = (u == K - 1);
@@ -259,8 +271,10 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
         }
       }
       static_assert((K & 1) == 1, "the weight-fragment ping-pong assumes an odd number of taps per row");
-      wait_vm0();                                        // this row's weight DMA (issued two rows ago) has landed
-      __builtin_amdgcn_s_barrier();
+      if (g % R == R - 1 || g == NG - 1) {
+        wait_vm0();                                      // the weight DMA issued AHEAD slot fills ago has landed
+        __builtin_amdgcn_s_barrier();
+      }
     }
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
