@@ -239,6 +239,13 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0), vmcnt / expcnt untouched
         __builtin_amdgcn_sched_barrier(0);
+        if (R > 1 && last_u && (g % R == R - 1 || g == NG - 1)) {
+          // Shared slots (k = 3): the next pair's weights were streamed ONE fill ahead, so they must be confirmed before
+          // this tap prefetches their first fragments; and every wave's last reads of the current slot (issued during the
+          // previous tap) have returned at this point, so the barrier also frees it for the fill the next row starts.
+          wait_vm0();
+          __builtin_amdgcn_s_barrier();
+        }
         if (u == 0) {                                    // K is odd: the previous row (or the prologue) left tap 0's set in b[1]
           b[0][0] = b[1][0];
           b[0][1] = b[1][1];
@@ -271,8 +278,8 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
         }
       }
       static_assert((K & 1) == 1, "the weight-fragment ping-pong assumes an odd number of taps per row");
-      if (g % R == R - 1 || g == NG - 1) {
-        wait_vm0();                                      // the weight DMA issued AHEAD slot fills ago has landed
+      if (R == 1) {
+        wait_vm0();                                      // the next row's weight DMA (issued two rows ago) has landed
         __builtin_amdgcn_s_barrier();
       }
     }
