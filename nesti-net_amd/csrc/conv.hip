@@ -278,11 +278,17 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
       constexpr int S_ = decltype(SS)::value, SR_ = decltype(SRR)::value, K_ = decltype(KK)::value;
       constexpr int lo = (K_ - 1) / 2;
       constexpr int log2S_ = (S_ == 8) ? 3 : (S_ == 4) ? 2 : 1;
+      // item -> (x-line, 4-channel group): a wave's four 16-lane groups are the four lines (y0, z0) of one 2 x 2 (y, z)
+      // cell, so that the 2^3 / 2 max-pool that may follow (mp_mode2) is an x-pair max in registers plus two
+      // cross-lane maxima (lane ^ 16, lane ^ 32) -- no second pass through LDS
+      constexpr int H_ = S_ / 2, log2H_ = log2S_ - 1;
 #pragma unroll 1
       for (int it = 0; it < 16 / S_; ++it) {
-        const int item = it * kThreads + tid;
-        const int line = item >> 4, cg = item & 15;
-        const int y = line & (S_ - 1), z = (line >> log2S_) & (S_ - 1);
+        const int cg = lane & 15, y0 = (lane >> 4) & 1, z0 = lane >> 5;
+        const int cell = it * 8 + wave;
+        const int cy = cell & (H_ - 1), cz = (cell >> log2H_) & (H_ - 1), cpt = cell >> (2 * log2H_);
+        const int y = 2 * cy + y0, z = 2 * cz + z0;
+        const int line = (((cpt << log2S_) + z) << log2S_) + y;
         const int row0 = line << log2S_;
         // separable box sum: add the K^2 neighbouring x-lines first, then one x window over the column sums
         float4 colsum[S_];
@@ -323,22 +329,51 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           }
         }
         const float4 bb = *reinterpret_cast<const float4*>(bias + nh * 64 + cg * 4);
+        const int col = out_col0 + nh * 64 + cg * 4;
+        float4 o[S_];
 #pragma unroll
         for (int x = 0; x < S_; ++x) {
           int nx = 0;
 #pragma unroll
           for (int c = 0; c < K_; ++c) nx += (x + c - lo >= 0 && x + c - lo < SR_) ? 1 : 0;
           const float inv = p.acc_scale / (float)max(1, nz * ny * nx);   // taps inside the volume (utils/tf_util.py:450-454); 0 only on dead rows
-          const float o[4] = {fmaxf(sum[x].x * inv + bb.x, act_floor), fmaxf(sum[x].y * inv + bb.y, act_floor),
-                              fmaxf(sum[x].z * inv + bb.z, act_floor), fmaxf(sum[x].w * inv + bb.w, act_floor)};
-          const long long gr = r0 + row0 + x;
-          if (gr < total_rows) {
-            const int col = out_col0 + nh * 64 + cg * 4;
-            if (out_esz == 4) {
-              *reinterpret_cast<float4*>(out_b + (gr * p.out_cstride + col) * 4) = make_float4(o[0], o[1], o[2], o[3]);
-            } else {
-              using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
-              store_act4<E>(out_b, gr * p.out_cstride, col, o[0], o[1], o[2], o[3], p.split);
+          o[x] = make_float4(fmaxf(sum[x].x * inv + bb.x, act_floor), fmaxf(sum[x].y * inv + bb.y, act_floor),
+                             fmaxf(sum[x].z * inv + bb.z, act_floor), fmaxf(sum[x].w * inv + bb.w, act_floor));
+        }
+        if (!p.mp_mode2) {
+#pragma unroll
+          for (int x = 0; x < S_; ++x) {
+            const long long gr = r0 + row0 + x;
+            if (gr < total_rows) {
+              if (out_esz == 4) {
+                *reinterpret_cast<float4*>(out_b + (gr * p.out_cstride + col) * 4) = o[x];
+              } else {
+                using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
+                store_act4<E>(out_b, gr * p.out_cstride, col, o[x].x, o[x].y, o[x].z, o[x].w, p.split);
+              }
+            }
+          }
+        } else {
+          // tf.nn.max_pool3d 2^3 / 2 (utils/tf_util.py:424-428) of the activated values: x pairs here, then the cell's other
+          // three lines from lanes ^ 16 (y) and ^ 32 (z); the cell's first 16 lanes store the pooled row segments
+          unsigned char* mp_b2 = reinterpret_cast<unsigned char*>(p.mp_out);
+#pragma unroll
+          for (int xc = 0; xc < H_; ++xc) {
+            float4 m = make_float4(fmaxf(o[2 * xc].x, o[2 * xc + 1].x), fmaxf(o[2 * xc].y, o[2 * xc + 1].y),
+                                   fmaxf(o[2 * xc].z, o[2 * xc + 1].z), fmaxf(o[2 * xc].w, o[2 * xc + 1].w));
+#pragma unroll
+            for (int d = 16; d <= 32; d <<= 1) {
+              m.x = fmaxf(m.x, __shfl_xor(m.x, d, 64)); m.y = fmaxf(m.y, __shfl_xor(m.y, d, 64));
+              m.z = fmaxf(m.z, __shfl_xor(m.z, d, 64)); m.w = fmaxf(m.w, __shfl_xor(m.w, d, 64));
+            }
+            const long long go = (r0 >> 3) + (((((long long)cpt << log2H_) + cz) << log2H_) + cy) * H_ + xc;
+            if (lane < 16 && go < (total_rows >> 3)) {
+              if (out_esz == 4) {
+                *reinterpret_cast<float4*>(mp_b2 + (go * p.mp_cstride + col) * 4) = m;
+              } else {
+                using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
+                store_act4<E>(mp_b2, go * p.mp_cstride, col, m.x, m.y, m.z, m.w, p.split);
+              }
             }
           }
         }
@@ -552,7 +587,8 @@ int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream) {
   if (p.mp_mode != 0 && (p.log2S < 1 || !p.mp_out)) NESTI_FAIL("launch_conv: fused max-pool needs a volume >= 2^3 and an output");
   if (p.s_real && !(p.s_real == 3 && p.log2S == 2)) NESTI_FAIL("launch_conv: s_real is the 3^3 grid inside a 4^3 index space only");
   if (p.s_real && p.pool_k == 3) NESTI_FAIL("launch_conv: fused 3^3 avg-pool is not built for the embedded 3^3 volume");
-  if (p.s_real && p.mp_mode != 0) NESTI_FAIL("launch_conv: the fused 2^3 max-pool does not apply to the 3^3 volume");
+  if (p.s_real && (p.mp_mode != 0 || p.mp_mode2 != 0)) NESTI_FAIL("launch_conv: the fused 2^3 max-pool does not apply to the 3^3 volume");
+  if (p.mp_mode2 != 0 && (p.pool_k <= 1 || !p.mp_out || p.log2S < 1)) NESTI_FAIL("launch_conv: mp_mode2 belongs to a fused avg-pool half with a pooled output");
   if (p.pool_k > 1 && !((p.log2S == 3 && p.pool_k == 3) || (p.log2S == 2 && (p.pool_k == 2 || p.pool_k == 3)) ||
                         (p.log2S == 1 && p.pool_k == 2)))
     NESTI_FAIL("launch_conv: fused pooling supports (S,k) in {(8,3),(4,3),(4,2),(2,2)}");

@@ -41,6 +41,8 @@ struct ConvParams {
   void* mp_out;        // [points * V/8, mp_cstride], same channel offsets as `out`
   int mp_cstride;
   int mp_mode;
+  int mp_mode2;        // 1: the conv4 half (fused avg-pool epilogue) writes ONLY its 2^3 / 2 max-pooled tensor, into mp_out at
+                       // out_coff2 -- the block is followed by max_pool3d and nobody reads conv4 at full resolution
   // k^3-tap layers: 1 = the 16 32-row MFMA tiles of a workgroup are (8x,2y,2z) blocks (8^3) / x-lines of the
   // 8 points (4^3), dealt to the 4 SIMDs as a Latin square so that the tiles a padding tap skips are spread evenly
   // over the matrix pipes (conv.hip: tile_row).  0 = tile t holds rows [32t, 32t+32).

@@ -128,6 +128,7 @@ struct Op {
   int in_buf = 0, in_coff = 0, out_buf = 0, out_coff = 0, out_coff2 = 0;
   int in_cstride = 0;          // 0: the input buffer's channel count; else a flattened view (FC on S^3 x C)
   int mp_buf = -1, mp_mode = 0; // fused 2^3 max-pool of the first tile group into this buffer (1: pooled only, 2: both)
+  int mp_mode2 = 0;             // 1: the conv4 half writes only its pooled tensor too (kernels.h: ConvParams::mp_mode2)
   int layer = -1;
   int C = 0, k = 0, log2S = 0;
   bool out_f32 = false;
@@ -150,6 +151,12 @@ struct Graph {
   Tower gate;
   std::vector<Tower> experts;
 };
+
+// A/B switch for same-box comparisons (NESTI_FUSE_CONV4_MAXPOOL=0: the standalone max-pool kernel for conv4's columns)
+bool fuse_conv4_maxpool() {
+  static const int v = [] { const char* e = getenv("NESTI_FUSE_CONV4_MAXPOOL"); return e ? atoi(e) : 1; }();
+  return v != 0;
+}
 
 struct Builder {
   Graph& g;
@@ -195,7 +202,10 @@ struct Builder {
     ChanMap c1; c1.C = Fp; for (int i = 0; i < F; ++i) c1.pos.push_back(i);
     conv(T, scope + "_conv1", 1, log2S, in_buf, 0, in, F, ob, 0, true, true, false, false,
          scope + "_conv4", Fp + Hp + Hp, k0);
-    if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 2; }
+    // conv4 behind a max-pool: when its avg-pool runs in the epilogue (k0 > 1) the 2^3 max is taken there as well and
+    // its full-resolution columns are never written; with k0 == 1 (plain columns) the small standalone kernel pools them
+    const bool fuse4 = then_maxpool && k0 > 1 && !s_real && fuse_conv4_maxpool();
+    if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 2; T.ops.back().mp_mode2 = fuse4 ? 1 : 0; }
     conv(T, scope + "_conv2", k0, log2S, ob, 0, c1, H, ob, Fp);
     if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 1; }
     conv(T, scope + "_conv3", k1, log2S, ob, 0, c1, H, ob, Fp + Hp);
@@ -207,9 +217,11 @@ struct Builder {
     for (int i = 0; i < F; ++i) out_map->pos.push_back(Fp + Hp + Hp + i);
     out_map->C = C;
     if (then_maxpool) {
-      Op op; op.kind = Op::MAX; op.in_buf = ob; op.out_buf = pb; op.in_coff = op.out_coff = Fp + Hp + Hp;
-      op.C = Fp; op.log2S = log2S;
-      T.ops.push_back(op);
+      if (!fuse4) {
+        Op op; op.kind = Op::MAX; op.in_buf = ob; op.out_buf = pb; op.in_coff = op.out_coff = Fp + Hp + Hp;
+        op.C = Fp; op.log2S = log2S;
+        T.ops.push_back(op);
+      }
       return pb;
     }
     return ob;
@@ -727,7 +739,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       const long long rows = (long long)rc.NB << (3 * d.log2S);
       p.m_tiles = pl.kind == 1 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
-      if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C * planes; p.mp_mode = op.mp_mode; }
+      if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C * planes; p.mp_mode = op.mp_mode; p.mp_mode2 = op.mp_mode2; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
       if (pl.kind == 1) {   // conv8_kernel: feature bits for same-box A/B runs (bit 0: early staging of the next chunk)
