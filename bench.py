@@ -33,7 +33,7 @@ from nesti_net_amd.pipeline import NormalEstimator  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x3": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md (bf16x3 issues 3 bf16 MFMAs per
 #                                                                               algorithmic multiply; the numerator stays algorithmic)
-MAX_BATCH = {"bf16x3": 32768, "f16x3": 32768, "f32": 8192}   # library batch caps by workspace: 3 planes / 4-byte activations
+MAX_BATCH = {"bf16x3": 33400, "f16x3": 33400, "f32": 8192}   # library batch caps by workspace (3 planes / 4-byte activations); 100k = 3 even batches
 
 
 def make_clouds(n_clouds, n_points, stream=False):
