@@ -138,3 +138,22 @@ def test_weight_container_roundtrip(tmp_path):
     W2, cfg2 = weights.load(p)
     assert list(W2) == list(W) and all(np.array_equal(W[k], W2[k]) for k in W)
     assert cfg2 == cfg
+
+
+def test_python_enums_follow_the_header():
+    """config.DTYPES / ARCH_* are the header's enumerators (include/nesti_hip.h), by name and value."""
+    import re
+    from nesti_net_amd import config
+    text = open(os.path.join(REPO, "include", "nesti_hip.h")).read()
+    enums = {}
+    for body in re.findall(r"enum\s*\{([^}]*)\}", text):
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        for name, val in re.findall(r"(NESTI_[A-Z0-9_]+)\s*=\s*(\d+)", body):
+            enums[name] = int(val)
+    want = {"f32": "NESTI_F32", "bf16": "NESTI_BF16", "f16": "NESTI_F16", "bf16x3": "NESTI_BF16X3", "f16x3": "NESTI_F16X3"}
+    assert set(config.DTYPES) == set(want)
+    for k, name in want.items():
+        assert config.DTYPES[k] == enums[name], k
+    for py, name in (("ARCH_EXPERTS", "NESTI_ARCH_EXPERTS"), ("ARCH_SINGLE", "NESTI_ARCH_SINGLE"),
+                     ("ARCH_MULTI", "NESTI_ARCH_MULTI"), ("ARCH_SWITCH", "NESTI_ARCH_SWITCH")):
+        assert getattr(config, py) == enums[name], py
