@@ -4,8 +4,15 @@
 A step = one pass of the whole hot path (search-grid build -> multi-scale ball query -> MuPS ->
 gating net -> top-1 expert net -> normals) over one batch of synthetic clouds that are already
 resident in HBM: at N GPUs the batch is N clouds of --points points, each cloud's query rows
-block-sharded over all N ranks and re-assembled with one RCCL all-gather per cloud, so every
-rank processes --points queries per step whatever N is (weak scaling, real collective).
+block-sharded over all N ranks and re-assembled with one RCCL all-gather per step, so every
+rank processes --points queries per step whatever N is (weak scaling, real collective).  With N > 1 (or --strong) a
+second leg times ONE cloud's rows sharded over the N ranks (the north star's "points of one cloud shard across the GPUs":
+strong scaling) and prints it as "strong" in the same line.
+
+The headline dtype is f16x3c: every output is computed in f16 hi + lo pairs (three MFMA products per multiply, f16x3) and
+the gating net additionally runs in plain f16 first as a filter (NESTI_F16X3C, include/nesti_hip.h) -- the mode that
+meets the north star's parity clause (see "parity": every arg-max difference and the 1 - cos distribution against the
+exact-fp32 mode over the whole timed cloud).  The plain 16-bit mode ("fast_mode", f16) is 1.9x faster and does NOT meet it.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -31,9 +38,10 @@ from nesti_net_amd import dist as ndist  # noqa: E402
 from nesti_net_amd.config import NestiConfig  # noqa: E402
 from nesti_net_amd.pipeline import NormalEstimator  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x3": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md (bf16x3 issues 3 bf16 MFMAs per
-#                                                                               algorithmic multiply; the numerator stays algorithmic)
-MAX_BATCH = {"bf16x3": 33400, "f16x3": 33400, "f32": 8192}   # library batch caps by workspace (3 planes / 4-byte activations); 100k = 3 even batches
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x3": 2500.0, "f16x3c": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
+# library batch caps by workspace (MB per query: f16 gate 2.0, f16x3 gate 5.9, f16x3 expert 3.8 -- nesti_tower_workspace_bytes)
+MAX_BATCH = {"bf16x3": 33400, "f16x3": 33400, "f16x3c": 50000, "f32": 8192}
+PRODUCTS = {"bf16": 1, "f16": 1, "f32": 1, "bf16x3": 3, "f16x3": 3}   # MFMA products per multiply
 
 
 def make_clouds(n_clouds, n_points, stream=False):
@@ -52,13 +60,6 @@ def make_clouds(n_clouds, n_points, stream=False):
     return out
 
 
-def rms_angle_deg(pred, gt):
-    """Unoriented RMS angle error in degrees (utils/evaluate.py:139-147)."""
-    pred = pred / np.maximum(np.linalg.norm(pred, axis=1, keepdims=True), 1e-12)
-    c = np.clip(np.abs((pred * gt).sum(1)), 0, 1)
-    return float(np.sqrt(np.mean(np.degrees(np.arccos(c)) ** 2)))
-
-
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -72,13 +73,14 @@ def _cpu_model():
 def cpu_baseline(cfg, W, pts, routing_frac):
     """The oracle (numpy/scipy/torch-CPU restatement of the reference, kind "port") timed on this host on a bounded
     sample of the same workload: ball query on 2048 queries of the 100k cloud, MuPS on 64 and the CNN
-    on 512 of them.  The gate and each of the 7 experts are timed separately on all 512 queries, which gives both legs
-    from one pass: the reference's evaluate-all-7-experts behaviour (test_n_est_w_experts.py:148) = gate + sum of the
-    experts, and top-1 = gate + the experts weighted by this run's routing histogram."""
+    on 384 of them.  The gate and each of the 7 experts are timed separately on all 384 queries, which gives both legs
+    from one pass: ``value`` = gate + the experts weighted by this run's routing histogram -- the same top-1 work the GPU
+    path does, so that GPU / CPU compares like with like -- and ``value_all7_experts`` = the reference's own
+    evaluate-all-7-experts behaviour (test_n_est_w_experts.py:148) = gate + sum of the experts."""
     from oracle import mups_ref, net_ref, patches_ref
     cores = min(os.cpu_count() or 1, 32)      # torch-CPU conv3d stops scaling (and regresses) well before 256 threads
     torch.set_num_threads(cores)
-    n_patch, n_mups, n_net = 2048, 64, 512
+    n_patch, n_mups, n_net = 2048, 64, 384
     tree = patches_ref.build_tree(pts)
     _, r_abs = patches_ref.patch_radii(pts, cfg.patch_radius)
     t = time.time()
@@ -104,61 +106,61 @@ def cpu_baseline(cfg, W, pts, routing_frac):
         t_exp.append((time.time() - t) / n_net)
     per_top1 = t_patch + t_mups + t_gate + float(np.dot(routing_frac, t_exp))
     per_all7 = t_patch + t_mups + t_gate + float(np.sum(t_exp))
-    return {"value": 1.0 / per_all7, "unit": "normals/sec", "cores": cores, "kind": "port", "cpu": _cpu_model(),
+    return {"value": 1.0 / per_top1, "unit": "normals/sec", "cores": cores, "kind": "port", "cpu": _cpu_model(),
             "host_cores": os.cpu_count(),
-            "value_all7_experts": 1.0 / per_all7, "value_top1": 1.0 / per_top1,
+            "value_top1": 1.0 / per_top1, "value_all7_experts": 1.0 / per_all7,
             "ms_per_query": {"ball_query_1_thread": t_patch * 1e3, "mups_numpy_fp32": t_mups * 1e3, "gate": t_gate * 1e3,
                              "experts": [x * 1e3 for x in t_exp]},
             "sample": "oracle/ on the same 100k cloud: scipy ball query %d queries (1 thread, like the reference's workers=0) + "
                       "numpy MuPS fp32 %d queries + torch-CPU fp32 gate and each of the 7 experts on %d queries (%d threads, "
-                      "batches of %d); value = the reference's evaluate-all-7 behaviour, value_top1 = gate + routed expert"
-                      % (n_patch, n_mups, n_net, cores, chunk)}
+                      "batches of %d); value = gate + routed expert (the work the GPU path does), value_all7_experts = the "
+                      "reference's evaluate-all-7 behaviour" % (n_patch, n_mups, n_net, cores, chunk)}
 
 
-def mups_only(args, cfg, dev):
-    """Config 1: 100k queries -> patches (HIP ball query) -> MuPS f32 [B,8,8,8,60].  MuPS is fp32-VALU bound
-    (SURVEY.md 8(d)): ~55 lane-ops x 256 threads per patch row; HBM bytes = 122 880 written + 18 432 read per query."""
+def mups_leg(points, steps, warmup, cfg, dev):
+    """BASELINE config 1: `points` queries -> patches (HIP ball query) -> MuPS f32 [B,8,8,8,60], timed with the library's
+    hipEvents.  MuPS is fp32-VALU bound: ~55 lane-ops x 256 threads per patch row; HBM
+    bytes = 122 880 written + 18 432 read per query.  Returns the JSON object (a leg of the default run, and the whole
+    output of --mups-only)."""
     from nesti_net_amd.model import mups_forward
     from nesti_net_amd.provider import CloudPatches
-    pts, _ = synth.make_cloud("ellipsoid", n=args.points, seed=1234)
+    pts, _ = synth.make_cloud("ellipsoid", n=points, seed=1234)
     cp = CloudPatches(pts, cfg, device=dev)
-    B = min(args.batch, 16384, args.points)
+    B = min(16384, points)
     lib = _lib.load()
-    p0, n0 = cp.build(0, min(B, args.points))                 # mean patch rows per query: measured once, outside the timed loop
+    p0, n0 = cp.build(0, B)                                   # mean patch rows per query: measured once, outside the timed loop
     res_rows = int(n0.sum().item())
     del p0, n0
 
     def step():
         done = 0
-        while done < args.points:
-            take = min(B, args.points - done)
+        while done < points:
+            take = min(B, points - done)
             p, n = cp.build(done, take)
             out = mups_forward(cfg, p, n, out_dtype="f32")
             done += take
         return out
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
     lib.nesti_profile_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize(dev)
     el = time.perf_counter() - t0
-    ms = (ctypes.c_double * 4)()
-    nl = (ctypes.c_longlong * 4)()
-    lib.nesti_profile_read(ms, nl)
+    ms, _ = _lib.profile_read(lib)
     lib.nesti_profile_enable(0)
-    q = args.points * args.steps
-    mups_s = ms[1] / 1e3
-    rows_per_q = res_rows / max(1, min(B, args.points)) + cfg.n_scales       # + the unmasked row n_eff per scale
+    q = points * steps
+    mups_s = ms["input"]["mups"] / 1e3
+    rows_per_q = res_rows / B + cfg.n_scales                                   # + the unmasked row n_eff per scale
     valu_ops = 55.0 * 256 * rows_per_q * q                                     # lane-ops, see csrc/mups.hip
-    print(json.dumps({
+    return {
         "metric": "MuPS queries/sec (patch extraction + MuPS only)", "value": q / el, "unit": "queries/sec", "n_gpus": 1,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True,
+        "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps, "higher_is_better": True,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE config 1: %d-point ellipsoid, 3 scales, 8^3 grid, f32 output" % args.points,
+        "config": {"workload": "BASELINE config 1: %d-point ellipsoid, 3 scales, 8^3 grid, f32 output" % points,
                    "mean_patch_rows_per_query": rows_per_q},
         "roofline": {"bound": "valu", "kernel": "mups_kernel", "achieved": valu_ops / mups_s / 1e12, "peak": 78.6,
                      "unit": "Tlane-op/s (fp32 VALU issue: 256 CU x 4 SIMD x 32 lanes x 2.4 GHz)",
@@ -167,23 +169,35 @@ def mups_only(args, cfg, dev):
                      # fp32 vector peak (which counts an FMA as two flops; the max / min / compare half of this mix cannot fuse)
                      "survey_flops_frac_of_157TFLOPs": 27.0 * 512 * rows_per_q * q / mups_s / 1e12 / 157.3,
                      "hbm_GBps": q * (122880 + 18432 + 12) / mups_s / 1e9, "hbm_frac_of_8TBps": q * 141324 / mups_s / 8e12,
-                     "kernel_ms_per_step": {"mups": ms[1] / args.steps, "patches": ms[3] / args.steps}}}))
-    return 0
+                     "kernel_ms_per_step": {"mups": ms["input"]["mups"] / steps, "patches": ms["input"]["patches"] / steps}}}
 
 
-def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, use_pg, timing, want_shard0=True):
+def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, use_pg, timing, want_shard0=True, strong=False):
     """W warm-up steps, then exactly ``steps`` timed steps between barrier + synchronize pairs; max over ranks.
-    Returns the elapsed seconds, the kernel-time categories (rank 0), the last cloud's gathered results, this rank's
-    results for its shard of cloud 0 (for the parity leg) and the model's MAC counts."""
+    ``strong``: a step is ONE cloud (clouds_np[0]) whose rows are sharded over the ranks (dist.estimate_sharded).
+    Returns the elapsed seconds, the kernel-time table (rank 0), the last cloud's gathered results, this rank's
+    results for its shard of cloud 0 (for the parity leg), the model's MAC counts and the two-stage gate's counters."""
     lib = _lib.load()
+    if strong:
+        clouds_np = clouds_np[:1]
     rank_rows = sum(ndist.max_shard(len(p), world) for p, _ in clouds_np)      # rows of all clouds on one rank
     est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=min(args.batch, rank_rows, MAX_BATCH.get(dtype, 1 << 30)),
                           use_graph=args.graph, n_streams=args.streams)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
+    res = {}
+    if dtype == "f16x3c":
+        # the gate margin: measured on a 1024-query sample of cloud 0 (every rank derives the same value), calibrate.py
+        from nesti_net_amd.calibrate import GATE_MARGIN_SIGMAS, calibrate_gate_margin
+        sp, sn = clouds[0].build(0, min(1024, clouds[0].patch_count))
+        res["gate_margin"] = {"tau": calibrate_gate_margin(est.net, sp, sn), "sigmas": GATE_MARGIN_SIGMAS,
+                              "calibration_queries": int(sp.shape[0])}
+        del sp, sn
 
     def step():
         for c in clouds:
             c.build_grid()                                    # search structure: part of the path
+        if strong:
+            return ndist.estimate_sharded(est, clouds[0])
         # this rank's row blocks of all clouds as one stream of batches + one all-gather (dist.estimate_sharded_many)
         return ndist.estimate_sharded_many(est, clouds)[-1]
 
@@ -196,6 +210,8 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     for _ in range(warmup):
         step()
     sync()
+    if dtype == "f16x3c":
+        est.net.cascade_stats(reset=True)
     if timing:
         lib.nesti_profile_enable(1)
     t0 = time.perf_counter()
@@ -208,13 +224,12 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     if use_pg:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    prof_ms = (ctypes.c_double * 4)()
-    prof_n = (ctypes.c_longlong * 4)()
     if timing:
-        lib.nesti_profile_read(prof_ms, prof_n)
+        res["prof_ms"], res["prof_n"] = _lib.profile_read(lib)
         lib.nesti_profile_enable(0)
-    res = {"elapsed": elapsed, "prof_ms": list(prof_ms), "prof_n": list(prof_n), "batch": est.batch,
-           "out": [t.cpu().numpy() for t in out]}
+    if dtype == "f16x3c":
+        res["cascade"] = est.net.cascade_stats()                      # rank 0's counters over the timed steps
+    res.update({"elapsed": elapsed, "batch": est.batch, "steps": steps, "out": [t.cpu().numpy() for t in out]})
     if rank == 0:
         if want_shard0:
             lo, hi = ndist.shard_range(clouds[0].patch_count, 0, world)
@@ -223,8 +238,9 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
         nom, use, iss = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         macs = {}
         for tw in range(-1, cfg.n_experts):
-            lib.nesti_model_macs(h, tw, ctypes.byref(nom), ctypes.byref(use), ctypes.byref(iss))
-            macs[tw] = (nom.value, use.value, iss.value)
+            for kind in range(-1, len(_lib.PROF_CONV)):
+                lib.nesti_model_macs(h, tw, kind, ctypes.byref(nom), ctypes.byref(use), ctypes.byref(iss))
+                macs[(tw, kind)] = (nom.value, use.value, iss.value)
         res["macs"] = macs
     torch.cuda.synchronize(dev)
     del clouds, est
@@ -249,6 +265,72 @@ def reference_run(args, cfg, W, cloud_np, dev, world):
     return out, (hi - lo) / el
 
 
+def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
+    """The MFMA roofline of one timed run, whole (all conv launches) and per kernel class.
+
+    achieved = ALGORITHMIC FLOP (2 x useful MACs: gate once + the routed expert once per query) / the
+    summed hipEvent time of the conv launches.  by_kernel additionally gives each class's MFMA-issued rate: what the
+    matrix pipe actually executed (padding taps it could not skip, channel padding, three products per multiply in the
+    pair modes, the gate's second pass over the rechecked queries in f16x3c)."""
+    macs, steps = run["macs"], run["steps"]
+    ms, nl = run["prof_ms"], run["prof_n"]
+    E = cfg.n_experts
+    rank0_pts = sum(ndist.shard_range(len(p), 0, world)[1] for p, _ in clouds_np) * steps
+    peak = PEAK_TFLOPS[dtype]
+    cas = run.get("cascade")
+    # (phase, MFMA products per multiply, queries that went through it)
+    if dtype == "f16x3c":
+        phases = [("gate", 1, cas["queries"]), ("recheck", 3, cas["rechecked"]), ("experts", 3, rank0_pts)]
+    else:
+        phases = [("gate", PRODUCTS[dtype], rank0_pts), ("experts", PRODUCTS[dtype], rank0_pts)]
+
+    def per_pt(kind, j, tower_set):          # MACs per query of class `kind` (-1: all), j: 0 nominal / 1 useful / 2 issued
+        if tower_set == "experts":
+            return sum(frac[e] * macs[(e, kind)][j] for e in range(E))
+        return macs[(-1, kind)][j]
+
+    by_kernel, conv_ms, conv_n = {}, 0.0, 0
+    for k, name in enumerate(_lib.PROF_CONV):
+        t_ms = sum(ms[ph][name] for ph in _lib.PROF_PHASES)
+        n = sum(nl[ph][name] for ph in _lib.PROF_PHASES)
+        conv_ms += t_ms
+        conv_n += n
+        alg = 2.0 * (per_pt(k, 1, "gate") + per_pt(k, 1, "experts")) * rank0_pts
+        issued = sum(2.0 * prod * per_pt(k, 2, "experts" if ph == "experts" else "gate") * q for ph, prod, q in phases)
+        by_kernel[name] = {"ms_per_step": t_ms / steps, "launches_per_step": n / steps,
+                           "algorithmic_gflop_per_query": alg / rank0_pts / 1e9,
+                           "algorithmic_tflops": alg / (t_ms / 1e3) / 1e12 if t_ms else None,
+                           "mfma_issued_tflops": issued / (t_ms / 1e3) / 1e12 if t_ms else None,
+                           "frac_algorithmic": alg / (t_ms / 1e3) / 1e12 / peak if t_ms else None,
+                           "frac_mfma_issued": issued / (t_ms / 1e3) / 1e12 / peak if t_ms else None}
+    conv_s = conv_ms / 1e3
+    tot = [2.0 * (per_pt(-1, j, "gate") + per_pt(-1, j, "experts")) * rank0_pts / conv_s / 1e12 for j in range(3)]
+    issued_all = sum(2.0 * prod * per_pt(-1, 2, "experts" if ph == "experts" else "gate") * q for ph, prod, q in phases)
+    # HBM bytes per conv launch from the committed PMC passes of THIS configuration (FETCH_SIZE / WRITE_SIZE in
+    # separate rocprofv3 runs of bench.py with the calibrated gate, gfx950-corrected: scripts/make_profiles.sh,
+    # scripts/summarize_pmc.py).  Counters cannot be read from inside the process, so the figure is quoted from
+    # the profile only when dtype, batch and routing match; otherwise null.
+    traffic, src = None, None
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        pmc_file = os.path.join(REPO, "profiles", name)
+        if traffic is None and os.path.exists(pmc_file):
+            pj = json.load(open(pmc_file))
+            if pj.get("dtype") == dtype and pj.get("batch") == run["batch"] and pj.get("calibrated_gate") == calibrated:
+                traffic = pj["kernels"]["conv"]["hbm_bytes_per_query"] * rank0_pts / max(1, conv_n)
+                src = "profiles/%s (separate --pmc passes of this bench configuration)" % name
+    return {
+        "bound": "mfma", "kernel": "conv8_kernel + conv_igemm_kernel (all conv3d/fc layers)", "achieved": tot[1], "peak": peak,
+        "unit": "TFLOP/s", "frac": tot[1] / peak, "traffic": traffic, "traffic_source": src,
+        "algorithmic_gflop_per_point": 2 * (per_pt(-1, 1, "gate") + per_pt(-1, 1, "experts")) / 1e9, "nominal_tflops": tot[0],
+        "mfma_issued_tflops": issued_all / conv_s / 1e12, "frac_mfma_issued": issued_all / conv_s / 1e12 / peak,
+        "launches": int(conv_n), "avg_launch_ms": conv_ms / max(1, conv_n),
+        "by_kernel": by_kernel,
+        "kernel_ms_per_step": {"conv": conv_ms / steps,
+                               **{c: sum(ms[ph][c] for ph in _lib.PROF_PHASES) / steps for c in ("mups", "pool", "patches")}},
+        "conv_ms_per_step_by_phase": {ph: sum(ms[ph][c] for c in _lib.PROF_CONV) / steps for ph in _lib.PROF_PHASES[1:]},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -256,15 +338,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=100000, help="points per cloud (= queries per rank per step)")
     ap.add_argument("--batch", type=int, default=100000,
-                    help="queries per library call (workspace ~1.7 MB per query in f16: a whole 100k-point cloud is one batch; "
-                         "+1.5 %% from 25 000 to 50 000 and +1.2 %% more to 100 000 -- the per-expert launches fill the chip in "
-                         "fewer, fuller rounds)")
-    ap.add_argument("--dtype", default="f16", choices=["bf16", "f16", "f16x3", "bf16x3", "f32"],
-                    help="f16 (default) meets the north star's 1e-5 cosine tolerance against the fp32 mode; bf16 does not")
+                    help="queries per library call, capped per dtype by the workspace (MAX_BATCH: 50 000 for f16x3c, a whole "
+                         "100k-point cloud for f16 / bf16 at ~2 MB per query)")
+    ap.add_argument("--dtype", default="f16x3c", choices=["f16x3c", "f16x3", "bf16x3", "f16", "bf16", "f32"],
+                    help="f16x3c (default): f16 hi + lo pairs with the two-stage gate -- meets the north star's parity clause "
+                         "(bit-exact arg-max up to fp32 ties, 1e-5 cosine: see 'parity'); f16x3: the same without the gate filter; "
+                         "f16 / bf16: plain 16-bit, faster, do NOT meet it (657 / 4 652 arg-max flips per 100k queries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (fp32-mode rerun of rank 0's shard of cloud 0)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short bf16 run ('secondary') and the f16x3 run ('north_star_mode')")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short runs of the other modes ('fast_mode' f16, 'full_pair_mode' f16x3) and the MuPS leg")
+    ap.add_argument("--bf16", action="store_true", help="add a short bf16 run ('bf16_mode': the dtype BASELINE config 2 names)")
+    ap.add_argument("--strong", action="store_true",
+                    help="also time ONE cloud's rows sharded over the ranks (always on when --gpus > 1): the 'strong' object")
     ap.add_argument("--stream-clouds", type=int, default=0,
                     help="BASELINE config 4: this many clouds of varying size/density in flight per step instead of one "
                          "--points cloud per rank (not the headline workload)")
@@ -288,19 +375,26 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if args.debug_single_device:
         local_rank = 0
+    use_pg = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
+    # the process group comes first: nothing below has touched the GPU yet except selecting the device RCCL binds to, and a
+    # rendezvous / RCCL failure ends the rank with a non-zero exit code right here (no retry, no re-exec)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    use_pg = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.debug_single_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)
+        try:
+            if args.debug_single_device:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
+        except Exception as e:      # noqa: BLE001
+            print("bench.py: rank %d: init_process_group failed: %r" % (rank, e), file=sys.stderr, flush=True)
+            sys.exit(1)
 
     cfg = NestiConfig()
     if args.mups_only:
-        return mups_only(args, cfg, dev)
+        print(json.dumps(mups_leg(args.points, args.steps, args.warmup, cfg, dev)))
+        return 0
     W = weights.synthetic_weights(cfg)
     clouds_np = make_clouds(args.stream_clouds, args.points, stream=True) if args.stream_clouds else make_clouds(world, args.points)
     if not args.uncalibrated_gate:
@@ -313,23 +407,23 @@ def main():
         W = calibrate_gate(cfg, W, sp, sn, device=dev)
         del cp, sp, sn
     timing = (rank == 0) and not args.no_kernel_timing
+    headline = not args.stream_clouds
     main_run = timed_run(args, cfg, W, clouds_np, args.dtype, args.steps, args.warmup, dev, world, rank, use_pg, timing,
                          want_shard0=not args.no_parity and args.dtype != "f32")
-    second = None
-    if not args.no_secondary and args.dtype == "f16" and not args.stream_clouds:
-        # the same workload in bf16 (the dtype BASELINE config 2 names), 3 timed steps: reported beside the headline with
-        # its own parity distribution -- it is faster but does not meet the 1e-5 cosine tolerance
-        second = timed_run(args, cfg, W, clouds_np, "bf16", 3, 1, dev, world, rank, use_pg, timing, want_shard0=not args.no_parity)
-
-    strict = None
-    if not args.no_secondary and args.dtype in ("f16", "bf16") and not args.stream_clouds:
-        # the same workload in the mode that MEETS the north star's tolerance (f16 hi+lo pairs, three MFMA products per
-        # multiply: NESTI_F16X3), 2 timed steps, with its parity object against the exact-fp32 mode
-        strict = timed_run(args, cfg, W, clouds_np, "f16x3", 2, 1, dev, world, rank, use_pg, timing, want_shard0=not args.no_parity)
+    strong = None
+    if headline and (world > 1 or args.strong):
+        strong = timed_run(args, cfg, W, clouds_np, args.dtype, max(2, min(args.steps, 5)), 1, dev, world, rank, use_pg, False,
+                           want_shard0=False, strong=True)
+    legs = {}
+    if headline and not args.no_secondary and world == 1:
+        # the other modes on the same workload, a few steps each, each with its own parity object against the fp32 mode
+        for key, dt, st in (("fast_mode", "f16", 3), ("full_pair_mode", "f16x3", 2)) + ((("bf16_mode", "bf16", 3),) if args.bf16 else ()):
+            if dt != args.dtype:
+                legs[key] = (dt, st, timed_run(args, cfg, W, clouds_np, dt, st, 1, dev, world, rank, use_pg, timing,
+                                               want_shard0=not args.no_parity))
 
     if rank == 0:
         elapsed = main_run["elapsed"]
-        prof_ms, prof_n = main_run["prof_ms"], main_run["prof_n"]
         total_normals = sum(len(p) for p, _ in clouds_np) * args.steps
         normals, expert, probs = main_run["out"]
         hist = np.bincount(expert, minlength=cfg.n_experts)
@@ -344,67 +438,46 @@ def main():
                                       if args.stream_clouds else str(args.points), world),
                        "points_per_cloud": args.points, "batch": main_run["batch"], "weights": "synthetic seed %d" % weights.WEIGHT_SEED,
                        "routing_histogram": hist.tolist(), "parallelism": "dp%d (query rows)" % world},
-            "rms_angle_deg_vs_analytic": rms_angle_deg(normals, clouds_np[-1][1]),
         }
+        if "cascade" in main_run:
+            c = main_run["cascade"]
+            res["gate_cascade"] = {**main_run["gate_margin"], **c, "rechecked_frac": c["rechecked"] / max(1, c["queries"]),
+                                   "tau_over_max_margin_err": c["tau"] / c["max_margin_err"] if c["max_margin_err"] else None,
+                                   "note": "f16 filter pass over every query, f16x3 gate over those whose f16 top-2 logit margin "
+                                           "< tau; max_margin_err = the f16 pass's largest error on a logit difference among the "
+                                           "rechecked queries of the timed steps (a flip of an unrechecked query needs >= tau)"}
         frac = hist / max(1, hist.sum())
-
-        def roofline(run, dtype, steps):
-            macs = run["macs"]
-            # rank 0's queries per step: its shard of every cloud; routing of the last cloud stands in for all
-            per_pt = [macs[-1][j] + sum(frac[e] * macs[e][j] for e in range(cfg.n_experts)) for j in range(3)]
-            rank0_pts = sum(ndist.shard_range(len(p), 0, world)[1] for p, _ in clouds_np) * steps
-            conv_s = run["prof_ms"][0] / 1e3
-            ach = [2.0 * per_pt[j] * rank0_pts / conv_s / 1e12 for j in range(3)]
-            peak = PEAK_TFLOPS[dtype]
-            # HBM bytes per conv launch from the committed PMC passes of THIS configuration (FETCH_SIZE / WRITE_SIZE in
-            # separate rocprofv3 runs of bench.py with the calibrated gate, gfx950-corrected: scripts/make_profiles.sh,
-            # scripts/summarize_pmc.py).  Counters cannot be read from inside the process, so the figure is quoted from
-            # the profile only when dtype, batch and routing match; otherwise null.
-            traffic, src = None, None
-            pmc_file = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
-            if os.path.exists(pmc_file):
-                pj = json.load(open(pmc_file))
-                if pj.get("dtype") == dtype and pj.get("batch") == run["batch"] and pj.get("calibrated_gate") == (not args.uncalibrated_gate):
-                    per_q = pj["kernels"]["conv"]["hbm_bytes_per_query"]
-                    traffic = per_q * rank0_pts / max(1, int(run["prof_n"][0]))
-                    src = "profiles/r02_pmc_traffic.json (separate --pmc passes of this bench configuration)"
-            return {
-                "bound": "mfma", "kernel": "conv8_kernel + conv_igemm_kernel (all conv3d/fc layers)", "achieved": ach[1], "peak": peak,
-                "unit": "TFLOP/s", "frac": ach[1] / peak, "traffic": traffic, "traffic_source": src,
-                "algorithmic_gflop_per_point": 2 * per_pt[1] / 1e9, "nominal_tflops": ach[0], "issued_tflops": ach[2],
-                "launches": int(run["prof_n"][0]), "avg_launch_ms": run["prof_ms"][0] / max(1, run["prof_n"][0]),
-                "kernel_ms_per_step": {k: run["prof_ms"][i] / steps for i, k in enumerate(_lib.PROF_CATEGORIES)},
-            }
-
+        cal = not args.uncalibrated_gate
         if timing:
-            res["roofline"] = roofline(main_run, args.dtype, args.steps)
+            res["roofline"] = roofline(main_run, args.dtype, cfg, clouds_np, world, frac, cal)
+        if strong is not None:
+            res["strong"] = {"scaling": "strong", "value": len(clouds_np[0][0]) * strong["steps"] / strong["elapsed"],
+                             "unit": "normals/sec", "steps": strong["steps"], "warmup": 1,
+                             "ms_per_step": 1e3 * strong["elapsed"] / strong["steps"], "batch": strong["batch"],
+                             "workload": "ONE %d-point cloud per step, its query rows block-sharded over %d rank(s), one all-gather "
+                                         "(dist.estimate_sharded)" % (len(clouds_np[0][0]), world)}
         ref = None
         if not args.no_parity and args.dtype != "f32":
             from nesti_net_amd import parity
             ref, ref_rate = reference_run(args, cfg, W, clouds_np[0][0], dev, world)
             res["parity"] = parity.compare(main_run["shard0"], ref)
             res["parity"]["dtype"] = args.dtype
-            # the exact-fp32 MFMA mode is the one that meets the north star's parity clause (arg-max bit-exact, 1e-5 cosine
-            # against the CPU oracle: tests/test_gpu_fixtures.py); its rate on the same cloud, one untimed-style pass
+            # the exact-fp32 MFMA mode is the one the CPU oracle is tied to (tests/test_gpu_fixtures.py); its rate on the same
+            # cloud, one untimed-style pass
             res["exact_mode"] = {"dtype": "f32", "value": ref_rate, "unit": "normals/sec (1 GPU, one pass over rank 0's shard)",
                                  "peak_tflops": PEAK_TFLOPS["f32"]}
-        if second is not None:
-            res["secondary"] = {"dtype": "bf16", "value": sum(len(p) for p, _ in clouds_np) * 3 / second["elapsed"],
-                                "unit": "normals/sec", "steps": 3, "warmup": 1, "ms_per_step": 1e3 * second["elapsed"] / 3}
+        for key, (dt, st, run) in legs.items():
+            res[key] = {"dtype": dt, "value": sum(len(p) for p, _ in clouds_np) * st / run["elapsed"], "unit": "normals/sec",
+                        "steps": st, "warmup": 1, "ms_per_step": 1e3 * run["elapsed"] / st, "batch": run["batch"]}
             if timing:
-                res["secondary"]["roofline"] = roofline(second, "bf16", 3)
+                res[key]["roofline"] = roofline(run, dt, cfg, clouds_np, world, frac, cal)
             if ref is not None:
                 from nesti_net_amd import parity
-                res["secondary"]["parity"] = parity.compare(second["shard0"], ref)
-        if strict is not None:
-            res["north_star_mode"] = {"dtype": "f16x3", "value": sum(len(p) for p, _ in clouds_np) * 2 / strict["elapsed"],
-                                      "unit": "normals/sec", "steps": 2, "warmup": 1, "ms_per_step": 1e3 * strict["elapsed"] / 2,
-                                      "batch": strict["batch"]}
-            if timing:
-                res["north_star_mode"]["roofline"] = roofline(strict, "f16x3", 2)
-            if ref is not None:
-                from nesti_net_amd import parity
-                res["north_star_mode"]["parity"] = parity.compare(strict["shard0"], ref)
+                res[key]["parity"] = parity.compare(run["shard0"], ref)
+        if headline and not args.no_secondary and world == 1:
+            m = mups_leg(args.points, 3, 1, cfg, dev)          # BASELINE config 1, driver-timed: the MuPS kernel against its VALU / HBM roofs
+            res["mups"] = {"value": m["value"], "unit": m["unit"], "ms_per_step": m["ms_per_step"], "steps": 3, "roofline": m["roofline"],
+                           "workload": m["config"]["workload"]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, W, clouds_np[0][0], frac)
         print(json.dumps(res))

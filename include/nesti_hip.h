@@ -37,7 +37,14 @@ extern "C" {
  * bf16 pairs hold 2^-17 relative; f16 pairs hold max(2^-23 relative, 3e-8 absolute) with the weights of each layer scaled
  * by a power of two into f16's normal range (undone in the epilogue): the mode that keeps test_n_est_w_experts.py's outputs
  * within the 1e-5 cosine / arg-max tolerance with two orders of magnitude to spare. */
-enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16X3 = 4 };
+enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16X3 = 4, NESTI_F16X3C = 5 };
+/* NESTI_F16X3C ("cascade", MODEL dtype only, gated models): everything that reaches the outputs is computed as in
+ * NESTI_F16X3 -- the experts, and the gating net for every query whose decision could depend on it -- but the gating net
+ * first runs in plain f16 as a FILTER: a query whose f16 top-2 logit margin is at least the gate margin tau keeps the f16
+ * arg-max (a flip would need an f16 logit error of tau), every other query is decided again by the f16x3 gating net.
+ * expert_out / normals_out are then those of NESTI_F16X3 as long as the f16 gate's error on a logit difference stays below
+ * tau, which every call re-measures on the queries it decides twice (nesti_model_cascade_stats); probs_out carries the
+ * f16 gate's probabilities for the queries that were not re-decided. */
 
 /* which graph nesti_model_create builds */
 enum {
@@ -144,6 +151,32 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
                        int n_tensors, int dtype, nesti_model_t** out);
 void nesti_model_destroy(nesti_model_t* m);
 
+/* ---- NESTI_F16X3C: the gate margin and the running statistics of the two-stage gate ---------------------------------
+ * tau is in units of the gating net's last-layer outputs (the values softmax sees, models/experts_n_est.py:174-177).
+ * nesti_model_cascade_stats synchronises `stream`, copies the counters accumulated by every forward call since the last
+ * reset and optionally resets them:
+ *   queries        rows that went through the gate,
+ *   rechecked      rows whose f16 top-2 margin was below tau (decided by the f16x3 gate),
+ *   changed        rechecked rows whose arg-max differs between the two gates,
+ *   max_margin_err largest |(l_a - l_k)_f16 - (l_a - l_k)_f16x3| over the rechecked rows and all experts k, a = the f16
+ *                  arg-max: the f16 gate's error on exactly the quantity tau guards.  It must stay well below tau.
+ *   sum_sq_pair_err / pairs: the same errors squared and summed over all (rechecked row, k != a) pairs, and their count:
+ *                  sqrt(sum / pairs) is the standard deviation sigma of the f16 pass's error on one logit difference (the
+ *                  errors are rounding noise: zero-mean, independent of the margin); tau is chosen as a multiple of it. */
+typedef struct {
+  uint64_t queries, rechecked, changed;
+  float max_margin_err;
+  float tau;
+  double sum_sq_pair_err;
+  uint64_t pairs;
+} nesti_cascade_stats_t;
+int nesti_model_set_gate_margin(nesti_model_t* m, float tau);
+int nesti_model_cascade_stats(const nesti_model_t* m, nesti_cascade_stats_t* out, int reset, void* stream);
+
+/* Workspace of ONE tower for `batch` queries, from the configuration alone (no device needed): tower = -1 the gating
+ * net, 0..E-1 an expert.  dtype as nesti_model_create (NESTI_F16X3C: the gate figure is the f16 filter's). */
+size_t nesti_tower_workspace_bytes(const nesti_config_t* cfg, int dtype, int tower, int batch);
+
 /* Scratch size for forward calls of up to max_batch points. */
 size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch);
 int nesti_model_mups_cstride(const nesti_model_t* m); /* channel stride of the internal MuPS tensor, in elements
@@ -232,18 +265,28 @@ int nesti_write_text_i32(const char* path, const int32_t* data, int64_t rows);
 /* ---- measurement support (bench.py's roofline leg; no reference counterpart) ------------
  * nesti_profile_enable(1) makes every kernel launch of the forward path record a pair of
  * hipEvents on its stream; nesti_profile_read() synchronises on them and returns, per
- * category, the summed kernel time in ms and the number of launches since enable.
+ * (phase, category), the summed kernel time in ms and the number of launches since enable:
+ * arrays of NESTI_PROF_PHASES * NESTI_PROF_CATEGORIES entries, index = phase * NESTI_PROF_CATEGORIES + category.
+ * Categories are kernels (the four conv categories are the layer classes of DESIGN.md 4.3 / 4.4); phases say which part
+ * of the forward pass launched them (NESTI_F16X3C: the gate's f16 filter pass counts as GATE, its f16x3 pass as RECHECK).
  * Not thread-safe; leave it off outside measurements. */
-enum { NESTI_PROF_CONV = 0, NESTI_PROF_MUPS = 1, NESTI_PROF_POOL = 2, NESTI_PROF_PATCHES = 3,
-       NESTI_PROF_CATEGORIES = 4 };
+enum { NESTI_PROF_CONV8_K5 = 0,   /* conv8_kernel, 5^3 taps at 8^3                                  */
+       NESTI_PROF_CONV8_K3 = 1,   /* conv8_kernel, 3^3 taps at 8^3                                  */
+       NESTI_PROF_TAPS = 2,       /* conv_igemm_kernel, k^3 taps at 4^3 / 2^3 (and 3^3-in-4^3)      */
+       NESTI_PROF_ONE_BY_ONE = 3, /* conv_igemm_kernel, 1x1x1 layers (+ fused avg-pool) and FC      */
+       NESTI_PROF_MUPS = 4, NESTI_PROF_POOL = 5, NESTI_PROF_PATCHES = 6, NESTI_PROF_CATEGORIES = 7 };
+enum { NESTI_PHASE_INPUT = 0,     /* search grid, ball query, MuPS                                  */
+       NESTI_PHASE_GATE = 1, NESTI_PHASE_RECHECK = 2, NESTI_PHASE_EXPERTS = 3, NESTI_PROF_PHASES = 4 };
 int nesti_profile_enable(int on);
-int nesti_profile_read(double* ms /*[NESTI_PROF_CATEGORIES]*/,
-                       long long* launches /*[NESTI_PROF_CATEGORIES]*/);
-/* Multiply-accumulates per point of one tower (tower = -1: gating net, 0..E-1: expert):
+int nesti_profile_read(double* ms /*[NESTI_PROF_PHASES * NESTI_PROF_CATEGORIES]*/,
+                       long long* launches /*[NESTI_PROF_PHASES * NESTI_PROF_CATEGORIES]*/);
+/* Multiply-accumulates per point of one tower (tower = -1: gating net, 0..E-1: expert), over the layers of conv
+ * category `kind` (NESTI_PROF_CONV8_K5 .. NESTI_PROF_ONE_BY_ONE; -1: all of them):
  *   nominal = dense conv as TensorFlow executes it (zero-padding taps included),
  *   useful  = taps that land inside the volume only (the algorithmic figure),
- *   issued  = what the MFMA kernels actually issue (channel padding included). */
-int nesti_model_macs(const nesti_model_t* m, int tower, double* nominal, double* useful,
+ *   issued  = what the MFMA kernels issue for ONE 16-bit product (channel padding and unskipped padding taps included;
+ *             the pair modes issue three such products per multiply). */
+int nesti_model_macs(const nesti_model_t* m, int tower, int kind, double* nominal, double* useful,
                      double* issued);
 
 #ifdef __cplusplus

@@ -26,6 +26,13 @@ class CShapeQueries(ctypes.Structure):
                 ("grid_ws_dev", ctypes.c_void_p), ("grid_ws_bytes", ctypes.c_size_t)]
 
 
+class CCascadeStats(ctypes.Structure):
+    """Mirror of ``nesti_cascade_stats_t``."""
+    _fields_ = [("queries", ctypes.c_uint64), ("rechecked", ctypes.c_uint64), ("changed", ctypes.c_uint64),
+                ("max_margin_err", ctypes.c_float), ("tau", ctypes.c_float),
+                ("sum_sq_pair_err", ctypes.c_double), ("pairs", ctypes.c_uint64)]
+
+
 class NestiError(RuntimeError):
     pass
 
@@ -49,6 +56,9 @@ SIGNATURES = {
     "nesti_model_describe": (_i, [_cfgp, ctypes.POINTER(_i), ctypes.POINTER(CTensor), _i]),
     "nesti_model_create": (_i, [_cfgp, ctypes.POINTER(CTensor), _i, _i, ctypes.POINTER(_vp)]),
     "nesti_model_destroy": (None, [_vp]),
+    "nesti_model_set_gate_margin": (_i, [_vp, ctypes.c_float]),
+    "nesti_model_cascade_stats": (_i, [_vp, ctypes.POINTER(CCascadeStats), _i, _vp]),
+    "nesti_tower_workspace_bytes": (_sz, [_cfgp, _i, _i, _i]),
     "nesti_workspace_bytes": (_sz, [_vp, _i]),
     "nesti_model_mups_cstride": (_i, [_vp]),
     "nesti_model_mups_rows": (_i, [_vp]),
@@ -64,10 +74,22 @@ SIGNATURES = {
     "nesti_estimate_normals_multi": (_i, [_vp, ctypes.POINTER(CShapeQueries), _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "nesti_profile_enable": (_i, [_i]),
     "nesti_profile_read": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
-    "nesti_model_macs": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+    "nesti_model_macs": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                               ctypes.POINTER(ctypes.c_double)]),
 }
-PROF_CATEGORIES = ("conv", "mups", "pool", "patches")
+PROF_CATEGORIES = ("conv8_k5", "conv8_k3", "taps_4_2", "one_by_one_fc", "mups", "pool", "patches")   # NESTI_PROF_*
+PROF_CONV = PROF_CATEGORIES[:4]
+PROF_PHASES = ("input", "gate", "recheck", "experts")                                               # NESTI_PHASE_*
+
+
+def profile_read(lib):
+    """``nesti_profile_read`` -> ({phase: {category: ms}}, {phase: {category: launches}})."""
+    n = len(PROF_PHASES) * len(PROF_CATEGORIES)
+    ms, nl = (ctypes.c_double * n)(), (ctypes.c_longlong * n)()
+    lib.nesti_profile_read(ms, nl)
+    k = len(PROF_CATEGORIES)
+    return ({ph: {c: ms[i * k + j] for j, c in enumerate(PROF_CATEGORIES)} for i, ph in enumerate(PROF_PHASES)},
+            {ph: {c: int(nl[i * k + j]) for j, c in enumerate(PROF_CATEGORIES)} for i, ph in enumerate(PROF_PHASES)})
 
 _lib = None
 

@@ -42,3 +42,28 @@ def calibrate_gate(cfg, W, points, n_eff, device="cuda:0", spread=2.0):
     out = dict(W)
     out["fc4noise/weights"], out["fc4noise/biases"] = w4n, b4n
     return out
+
+
+GATE_MARGIN_SIGMAS = 7.0     # tau = this many standard deviations of the f16 gate's error on a logit difference
+GATE_MARGIN_OVER_MAX = 1.25  # ... and at least this x the largest such error seen on the calibration sample
+
+
+def calibrate_gate_margin(net, points, n_eff, sigmas=GATE_MARGIN_SIGMAS, over_max=GATE_MARGIN_OVER_MAX, floor=1e-3):
+    """Set the gate margin tau of an 'f16x3c' :class:`NestiNet` (``nesti_model_set_gate_margin``) from a sample of queries
+    (``points`` [B,S*P,3] / ``n_eff`` [B,S] device tensors).
+
+    With the margin at infinity every query of the sample goes through both gating passes, which measures the plain-f16
+    pass's error on the logit differences against its own arg-max -- the only way it can flip an arg-max.  That error is
+    rounding noise: zero-mean, independent of the margin itself and Gaussian to the eye (on the bench's 100k cloud sigma =
+    0.021, the largest of 600 000 pair errors 0.124 = 5.9 sigma), so a query that is NOT rechecked (f16 margin >= tau =
+    ``sigmas`` x sigma) has its arg-max flipped with probability < (E - 1) x P(|N(0, 1)| > 7) = 1.5e-11: one in 10^5
+    clouds of 100k points.  Every later forward call re-measures sigma and the largest error on the queries it decides
+    twice (:meth:`NestiNet.cascade_stats`; those are an unbiased sample because the error does not depend on the margin),
+    so a margin that has become too small for the data shows up as ``max_margin_err`` approaching tau.  Returns tau."""
+    net.cascade_stats(reset=True)
+    net.set_gate_margin(1e30)
+    net.gate(net.mups(points, n_eff))
+    st = net.cascade_stats(reset=True)
+    tau = max(float(sigmas) * st["sigma"], float(over_max) * st["max_margin_err"], float(floor))
+    net.set_gate_margin(tau)
+    return tau

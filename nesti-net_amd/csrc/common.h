@@ -31,6 +31,8 @@ static inline size_t dtype_size(int dt) { return dt == NESTI_F32 ? 4 : 2; }
 // planes [hi | lo | hi] (192 elements), and the packed weights the matching K order [W_hi ; W_hi ; W_lo], so that the
 // unchanged K loop accumulates hi*W_hi + lo*W_hi + hi*W_lo.  Writers emit the planes (split_col / split_pack2 below).
 // NESTI_F16X3: the same with f16 pairs and the f16 kernels.
+// NESTI_F16X3C is NESTI_F16X3 everywhere except in the gating net's first pass (model.hip: gate_cascade)
+static inline int main_dtype(int dt) { return dt == NESTI_F16X3C ? NESTI_F16X3 : dt; }
 static inline int kernel_dtype(int dt) { return dt == NESTI_BF16X3 ? NESTI_BF16 : dt == NESTI_F16X3 ? NESTI_F16 : dt; }
 static inline int act_planes(int dt) { return (dt == NESTI_BF16X3 || dt == NESTI_F16X3) ? 3 : 1; }
 constexpr int kSplitGroup = 64;
@@ -132,6 +134,7 @@ uint16_t host_f32_to_f16(float f);
 float host_f16_to_f32(uint16_t h);
 
 // ---- optional kernel timing (model.hip) -----------------------------------------
+void prof_phase(int phase);                                 // NESTI_PHASE_*: what the following launches are booked under
 int prof_begin(int category, hipStream_t st);              // returns a token for prof_end (-1: nothing recorded)
 void prof_end(int category, int token, hipStream_t st);
 

@@ -62,7 +62,12 @@ __device__ __forceinline__ uint4 lds128(unsigned addr) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-template <int DT, int K>
+// X3 (pair modes, model.hip: PackedLayer::x3n): the K chunk is 16 channels -- an LDS row holds [hi k0..15 | lo k0..15] of the
+// activation pair (staged from planes 0 and 1 of the [hi | lo | hi] row groups) and a weight row [W_hi k0..15 | W_lo k0..15]
+// -- and a tap multiplies hi * W_hi + lo * W_hi + hi * W_lo from ONE set of fragment reads: three MFMAs per 2 + 2/8
+// ds_read_b128 instead of two, and a third fewer (chunk, tap) steps, barriers and staged bytes than running the pair as
+// three planes through the plain kernel.
+template <int DT, int K, bool X3>
 __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
   for (int h = 0; h < 2; ++h) {
     const int pt = 2 * h + (st_row >> 3), x = st_row & 7;
     const int kslot = (lane & 3) ^ pt;                   // inverse swizzle on the SOURCE (LDS-DMA writes lane-linear)
-    a_voff[h] = (unsigned)((pt * 512 + x) * p.in_cstride * kEsz + kslot * 16);
+    a_voff[h] = (unsigned)((pt * 512 + x) * p.in_cstride * kEsz + (X3 ? (kslot & 1) * 16 + (kslot >> 1) * (2 * kSplitGroup) : kslot * 16));
     a_ok[h] = pt < np_here;
   }
   // tiles (bit j) of this wave whose slots are staged; split so that part of the next chunk can be prefetched while the
@@ -117,7 +122,9 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
     for (int j = 0; j < 8; ++j) {
       if (!(tiles & (1u << j))) continue;
       const int y = (wave - j) & 7;                      // tile (y, z = j) of this wave
-      const unsigned char* src = in_b + (size_t)((j * 64 + y * 8) * p.in_cstride) * kEsz + (size_t)c * 64;
+      // X3: chunk c = channels [16 c, 16 c + 16) of 64-channel group c >> 2, whose planes sit 128 B apart in a 384-B run
+      const unsigned char* src = in_b + (size_t)((j * 64 + y * 8) * p.in_cstride) * kEsz +
+                                 (X3 ? (size_t)(c >> 2) * (6 * kSplitGroup) + (size_t)(c & 3) * 32 : (size_t)c * 64);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         if (a_ok[h]) glds16(src + a_voff[h], lds0 + kAOff + (wave * 8 + j) * kTileBytes + h * 1024);
@@ -261,14 +268,16 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
           if (!last_u) {
             if (m_mm & (1u << j)) {
               mma<DT>(acc[j], a[j][0], bc[0]);
-              mma<DT>(acc[j], a[j][1], bc[1]);
+              mma<DT>(acc[j], a[j][1], X3 ? bc[0] : bc[1]);
+              if (X3) mma<DT>(acc[j], a[j][0], bc[1]);
               a[j][0] = lds128(nb0 + j * kTileBytes);
               a[j][1] = lds128(nb1 + j * kTileBytes);
             }
           } else {
             if (m_mm & (1u << j)) {
               mma<DT>(acc[j], a[j][0], bc[0]);
-              mma<DT>(acc[j], a[j][1], bc[1]);
+              mma<DT>(acc[j], a[j][1], X3 ? bc[0] : bc[1]);
+              if (X3) mma<DT>(acc[j], a[j][0], bc[1]);
             }
             if (m_rd & (1u << j)) {
               a[j][0] = lds128(nb0 + j * kTileBytes);
@@ -355,28 +364,33 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
   epi_pass(std::integral_constant<int, 1>{});
 }
 
-template <int DT, int K>
+template <int DT, int K, bool X3>
 int launch_conv8_one(const ConvParams& p, hipStream_t stream) {
   constexpr int kMaxDevices = 64;
   static bool attr_set[kMaxDevices] = {};
   int dev = 0;
   NESTI_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
-    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8_kernel<DT, K>),
+    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8_kernel<DT, K, X3>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLds8));
     if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
   }
   const int groups = (p.m_tiles + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * p.n_tiles)), block(kThreads8);
-  hipLaunchKernelGGL((conv8_kernel<DT, K>), grid, block, kLds8, stream, p);
+  hipLaunchKernelGGL((conv8_kernel<DT, K, X3>), grid, block, kLds8, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 template <int DT>
 int launch_conv8_dt(const ConvParams& p, int k, hipStream_t stream) {
-  if (k == 5) return launch_conv8_one<DT, 5>(p, stream);
-  if (k == 3) return launch_conv8_one<DT, 3>(p, stream);
+  if constexpr (DT != NESTI_F32) {
+    if (p.x3native && k == 5) return launch_conv8_one<DT, 5, true>(p, stream);
+    if (p.x3native && k == 3) return launch_conv8_one<DT, 3, true>(p, stream);
+  }
+  if (p.x3native) NESTI_FAIL("launch_conv8: the pair-native K loop is for the 16-bit kernels");
+  if (k == 5) return launch_conv8_one<DT, 5, false>(p, stream);
+  if (k == 3) return launch_conv8_one<DT, 3, false>(p, stream);
   NESTI_FAIL("launch_conv8: kernel size must be 3 or 5");
 }
 

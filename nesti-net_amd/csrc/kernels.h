@@ -50,6 +50,8 @@ struct ConvParams {
   // NESTI_BF16X3 / NESTI_F16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (three planes per
   // 64-channel group); out_coff / out_coff2 stay logical and every 16-bit store goes through split_col + three planes.
   int split;
+  int x3native;        // pair modes, conv8_kernel: K chunks of 16 channels [hi | lo] with three MFMAs per fragment set (conv8.hip: X3)
+                       // instead of the three planes as 3 x the channels; the packed weights follow (model.hip: PackedLayer::x3n)
   float acc_scale;     // the accumulators are multiplied by this before the bias (1, or 2^-s when the layer's packed weights
                        // carry a 2^s scale: NESTI_F16X3 keeps the weight pairs in f16's normal range that way)
   int8_t tap[kMaxTaps][4];   // dz, dy, dx, -
@@ -80,6 +82,13 @@ int launch_maxpool3s2(const PoolParams& p, int dtype, hipStream_t stream);
 int launch_gate_finish(const float* logits, int lstride, int B, int E, float* probs,
                        int32_t* expert, int32_t* counts /*[E] or NULL*/,
                        int32_t* lists /*[E][B] or NULL*/, hipStream_t stream);
+// NESTI_F16X3C, stage 1 / stage 2 of the two-stage gate (pool.hip): keep [B, NESTI_MAX_EXPERTS] f32, flag_list [B],
+// round_counts [n_rounds] = flagged rows of each `cap`-sized recheck round, cstat = the model's device counters
+int launch_gate_flag(const float* logits, int lstride, int B, int E, float tau, float* probs, int32_t* expert, float* keep,
+                     int32_t* flag_count, int32_t* flag_list, int cap, int n_rounds, int32_t* round_counts,
+                     unsigned long long* cstat, hipStream_t stream);
+int launch_gate_recheck(const float* logits, int lstride, const int32_t* flag_list, const int32_t* count_ptr, int cap, int E,
+                        const float* keep, float* probs, int32_t* expert, unsigned long long* cstat, hipStream_t stream);
 // ms_sw_n_est's switch (models/ms_sw_n_est.py:80-82): noise = logits[b*lstride]; expert = noise < threshold ? 0 : 1;
 // probs[b] = noise (one column); optional routing lists over the 2 towers.
 int launch_switch_finish(const float* logits, int lstride, int B, float threshold, float* probs,

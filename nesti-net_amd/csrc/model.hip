@@ -10,6 +10,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <regex>
 #include <string>
 #include <vector>
 
@@ -26,12 +27,14 @@ void set_error(const std::string& msg) { g_error = msg; }
 // ------------------------------------------------------------------------------------------
 // optional per-category kernel timing with hipEvents on the launch stream (bench.py roofline leg)
 // ------------------------------------------------------------------------------------------
+constexpr int kProfSlots = NESTI_PROF_PHASES * NESTI_PROF_CATEGORIES;   // slot = phase * NESTI_PROF_CATEGORIES + category
 struct ProfState {
   bool on = false;
+  int phase = NESTI_PHASE_INPUT;     // set by the forward path (prof_phase); launches are booked under it
   std::vector<hipEvent_t> pool;      // recycled events
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[NESTI_PROF_CATEGORIES];
-  double ms[NESTI_PROF_CATEGORIES] = {0};
-  long long launches[NESTI_PROF_CATEGORIES] = {0};
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> spans[kProfSlots];
+  double ms[kProfSlots] = {0};
+  long long launches[kProfSlots] = {0};
 };
 static ProfState g_prof;
 static std::mutex g_prof_mu;   // forward calls may come from several host threads (one stream each)
@@ -49,23 +52,29 @@ static bool prof_capturing(hipStream_t st) {
   if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
   return cs != hipStreamCaptureStatusNone;
 }
-// prof_begin returns a token for prof_end (-1: nothing recorded)
+void prof_phase(int phase) { if (g_prof.on) g_prof.phase = phase; }
+// prof_begin returns a token for prof_end (-1: nothing recorded): slot * 2^20 + index of the span within the slot
 int prof_begin(int cat, hipStream_t st) {
   if (!g_prof.on || prof_capturing(st)) return -1;
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  // the input kernels are launched between forward passes, whatever phase the last one ended in
+  const int phase = (cat == NESTI_PROF_MUPS || cat == NESTI_PROF_PATCHES) ? NESTI_PHASE_INPUT : g_prof.phase;
+  const int slot = phase * NESTI_PROF_CATEGORIES + cat;
+  if (g_prof.spans[slot].size() >= (1u << 20)) return -1;
   hipEvent_t a = prof_event(), b = prof_event();
   (void)hipEventRecord(a, st);
-  g_prof.spans[cat].push_back({a, b});
-  return (int)g_prof.spans[cat].size() - 1;
+  g_prof.spans[slot].push_back({a, b});
+  return (slot << 20) | ((int)g_prof.spans[slot].size() - 1);
 }
-void prof_end(int cat, int token, hipStream_t st) {
+void prof_end(int, int token, hipStream_t st) {
   if (token < 0) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  if (token < (int)g_prof.spans[cat].size()) (void)hipEventRecord(g_prof.spans[cat][token].second, st);
+  const int slot = token >> 20, idx = token & ((1 << 20) - 1);
+  if (slot < kProfSlots && idx < (int)g_prof.spans[slot].size()) (void)hipEventRecord(g_prof.spans[slot][idx].second, st);
 }
 static void prof_collect() {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (int c = 0; c < NESTI_PROF_CATEGORIES; ++c) {
+  for (int c = 0; c < kProfSlots; ++c) {
     for (auto& sp : g_prof.spans[c]) {
       (void)hipEventSynchronize(sp.second);
       float ms = 0.f;
@@ -420,6 +429,7 @@ struct PackedLayer {
   float* bias = nullptr;
   int TN = 64, n_tiles = 0, split_tile = 0, n_chunks = 0, n_taps = 0;
   int kind = 0;              // 0: conv_igemm_kernel (conv.hip), 1: conv8_kernel (conv8.hip: 4 points per workgroup)
+  bool x3n = false;          // pair modes on conv8_kernel: 16-channel K chunks [hi | lo] / [W_hi | W_lo], three MFMAs per fragment set
   float acc_scale = 1.0f;    // 2^-s when the packed weights carry a 2^s scale (NESTI_F16X3)
   int8_t tap[kMaxTaps][4];
 };
@@ -429,13 +439,21 @@ struct PackedLayer {
 
 struct nesti_model {
   nesti::Graph graph;
-  int dtype = NESTI_BF16;
+  int dtype = NESTI_BF16;                      // compute dtype of everything that reaches the outputs (NESTI_F16X3C -> NESTI_F16X3)
   std::vector<nesti::PackedLayer> packed;
+  // NESTI_F16X3C: the gating net's layers once more in plain f16 (indexed like `packed`, other entries empty), the gate
+  // margin and the device counters of the two-stage gate (include/nesti_hip.h: nesti_cascade_stats_t)
+  bool cascade = false;
+  std::vector<nesti::PackedLayer> packed_fast;
+  float tau = 0.25f;
+  unsigned long long* cstat = nullptr;
   ~nesti_model() {
-    for (auto& p : packed) {
-      if (p.wpk) (void)hipFree(p.wpk);
-      if (p.bias) (void)hipFree(p.bias);
-    }
+    for (auto* v : {&packed, &packed_fast})
+      for (auto& p : *v) {
+        if (p.wpk) (void)hipFree(p.wpk);
+        if (p.bias) (void)hipFree(p.bias);
+      }
+    if (cstat) (void)hipFree(cstat);
   }
 };
 
@@ -511,6 +529,36 @@ bool use_conv8(const LayerDesc& d) {
   return (d.k == 5 && mode >= 1) || (d.k == 3 && mode >= 2);
 }
 
+// Error attribution in the pair modes (scripts/exp_attribution.py): NESTI_X3_PLAIN = "regex[:bits],regex[:bits],..." -- a layer
+// whose scope matches drops the products named by bits (1: lo * W_hi, 2: hi * W_lo; default 3 = both, i.e. the layer
+// computes what the plain 16-bit mode computes) by packing zeros into those weight planes.  Read at every model creation.
+int x3_drop_mask(const LayerDesc& d) {
+  const char* e = getenv("NESTI_X3_PLAIN");
+  if (!e || !*e) return 0;
+  std::string spec(e);
+  int mask = 0;
+  size_t pos = 0;
+  while (pos <= spec.size()) {
+    size_t end = spec.find(',', pos);
+    if (end == std::string::npos) end = spec.size();
+    std::string item = spec.substr(pos, end - pos);
+    pos = end + 1;
+    if (item.empty()) continue;
+    int bits = 3;
+    const size_t colon = item.rfind(':');
+    if (colon != std::string::npos && colon + 1 < item.size() && isdigit((unsigned char)item[colon + 1])) {
+      bits = atoi(item.c_str() + colon + 1) & 3;
+      item = item.substr(0, colon);
+    }
+    try {
+      const std::regex re(item);
+      if (std::regex_search(d.scope, re) || (!d.scope2.empty() && std::regex_search(d.scope2, re))) mask |= bits;
+    } catch (const std::regex_error&) {
+    }
+  }
+  return mask;
+}
+
 int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer* pl) {
   const int n_parts = d.scope2.empty() ? 1 : 2;
   Folded parts[2];
@@ -535,8 +583,13 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
   // NESTI_BF16X3 / NESTI_F16X3 (common.h): K runs over the physical input row -- per 64-channel group the planes [hi | lo | hi] -- and
   // the weights follow it as [W_hi ; W_hi ; W_lo], so the unchanged K loop accumulates hi*W_hi + lo*W_hi + hi*W_lo
   const int planes = act_planes(dtype);
-  const int K_phys = d.Cin_p * planes;
+  const int drop = planes == 3 ? x3_drop_mask(d) : 0;
   pl->kind = use_conv8(d) ? 1 : 0;
+  // NESTI_X3_NATIVE=0: the pair modes run conv8_kernel on the three planes like every other kernel (same-box A/B, and the
+  // attribution sweep, whose per-product switches need the plane layout)
+  static const bool x3_native = [] { const char* e = getenv("NESTI_X3_NATIVE"); return e ? atoi(e) != 0 : true; }();
+  pl->x3n = pl->kind == 1 && planes == 3 && x3_native && drop == 0;
+  const int K_phys = pl->x3n ? d.Cin_p * 2 : d.Cin_p * planes;   // x3n: [hi 16 | lo 16] per chunk
   const int row_bytes = pl->kind == 1 ? 64 : kRowBytes;   // bytes of one K chunk of one row
   const int KC = row_bytes / (int)esz;
   pl->TN = pl->kind == 1 ? 32 : (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
@@ -584,9 +637,11 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
         const float* wt = f.w + (size_t)tap_widx[t] * d.cin * d.cout;
         for (int kc = 0; kc < KC; ++kc) {
           const int q = ch * KC + kc;                        // physical K position
-          const int plane = planes == 1 ? 0 : (q % (3 * kSplitGroup)) / kSplitGroup;
-          const int cr = inv[planes == 1 ? q : (q / (3 * kSplitGroup)) * kSplitGroup + q % kSplitGroup];
+          // weight plane of this K position (0 / 1: W_hi, 2: W_lo) and the padded input channel it multiplies
+          const int plane = pl->x3n ? (kc < 16 ? 0 : 2) : planes == 1 ? 0 : (q % (3 * kSplitGroup)) / kSplitGroup;
+          const int cr = inv[pl->x3n ? ch * 16 + (kc & 15) : planes == 1 ? q : (q / (3 * kSplitGroup)) * kSplitGroup + q % kSplitGroup];
           if (cr < 0) continue;
+          if ((plane == 1 && (drop & 1)) || (plane == 2 && (drop & 2))) continue;
           const float* wrow = wt + (size_t)cr * d.cout;
           const int slot = kc / per_slot, within = kc % per_slot;
           for (int nl = 0; nl < pl->TN; ++nl) {
@@ -703,16 +758,25 @@ int conv_remap(int k, int log2S, int n_taps) {
   return (log2S == 2 || k >= 4) ? 1 : 0;
 }
 
+// which NESTI_PROF_* conv category a layer's launch is booked under
+int conv_category(const LayerDesc& d, const PackedLayer& pl) {
+  if (pl.kind == 1) return d.k == 5 ? NESTI_PROF_CONV8_K5 : NESTI_PROF_CONV8_K3;
+  return pl.n_taps > 1 ? NESTI_PROF_TAPS : NESTI_PROF_ONE_BY_ONE;
+}
+
 struct RunCtx {
   const nesti_model* m;
   int NB;                        // capacity (points)
   const int32_t* npoints_ptr;    // device-side live count or NULL
   const int32_t* point_index;    // gather for reads of bufs 0/1, or NULL
   hipStream_t stream;
+  bool fast = false;             // NESTI_F16X3C filter pass: this tower runs in plain f16 on rc.m->packed_fast while the
+                                 // MuPS tensor it reads keeps the model's pair layout (only the hi plane is read)
 };
 
 int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* ws, size_t ws_bytes, float** out) {
-  const int dtype = rc.m->dtype;
+  const int dtype = rc.fast ? NESTI_F16 : rc.m->dtype;
+  const int x0_planes = act_planes(rc.m->dtype);
   std::vector<unsigned char*> ptr(T.bufs.size(), nullptr);
   ptr[0] = (unsigned char*)X0;
   const Placement P = place_tower(T, rc.NB, dtype);
@@ -722,7 +786,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
     const bool ext_in = op.in_buf < 1;
     if (op.kind == Op::CONV) {
       const LayerDesc& d = rc.m->graph.layers[op.layer];
-      const PackedLayer& pl = rc.m->packed[op.layer];
+      const PackedLayer& pl = rc.fast ? rc.m->packed_fast[op.layer] : rc.m->packed[op.layer];
       ConvParams p;
       memset(&p, 0, sizeof(p));
       p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf]; p.wpk = pl.wpk; p.bias = pl.bias;
@@ -732,10 +796,11 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       // offsets stay logical (kernels.h: ConvParams::split); an fp32 output buffer is an ordinary one
       const int planes = act_planes(dtype);
       p.split = planes > 1 ? 1 : 0;
-      p.in_cstride = (op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C) * planes; p.in_coff = op.in_coff * planes;
+      const int in_planes = ext_in ? x0_planes : planes;
+      p.in_cstride = (op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C) * in_planes; p.in_coff = op.in_coff * in_planes;
       p.out_cstride = T.bufs[op.out_buf].C * (op.out_f32 ? 1 : planes); p.out_coff = op.out_coff;
       p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S; p.s_real = d.s_real;
-      p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0; p.acc_scale = pl.acc_scale;
+      p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0; p.acc_scale = pl.acc_scale; p.x3native = pl.x3n ? 1 : 0;
       const long long rows = (long long)rc.NB << (3 * d.log2S);
       p.m_tiles = pl.kind == 1 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
@@ -746,10 +811,11 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
         static const int flags = [] { const char* e = getenv("NESTI_CONV8_FLAGS"); return e ? atoi(e) : 1; }();
         p.remap = flags;
       }
-      const int tok = prof_begin(NESTI_PROF_CONV, rc.stream);
+      const int cat = conv_category(d, pl);
+      const int tok = prof_begin(cat, rc.stream);
       const int rcv = pl.kind == 1 ? launch_conv8(p, kernel_dtype(dtype), d.k, rc.stream)
                                    : launch_conv(p, kernel_dtype(dtype), pl.TN, rc.stream);
-      prof_end(NESTI_PROF_CONV, tok, rc.stream);
+      prof_end(cat, tok, rc.stream);
       if (rcv) return 1;
     } else {
       PoolParams p;
@@ -776,14 +842,20 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
 // channel stride of the MuPS rows the towers read, in elements (pair modes: three planes per 64-channel group)
 int mups_stride(const nesti_model* m) { return m->graph.mups_cstride * act_planes(m->dtype); }
 
+// NESTI_F16X3C: the f16x3 gate re-decides the flagged rows `cap` at a time (its workspace is 3x the filter's per row, and
+// only a fraction of a batch is flagged): small batches in one round, large ones in quarters
+int cascade_cap(int NB) { return NB <= 4096 ? NB : (int)align_up((size_t)(NB + 3) / 4, 256); }
+int cascade_rounds(int NB) { return (NB + cascade_cap(NB) - 1) / cascade_cap(NB); }
+
 size_t max_tower_bytes(const nesti_model* m, int NB) {
-  size_t t = tower_bytes(m->graph.gate, NB, m->dtype);
+  size_t t = m->cascade ? std::max(tower_bytes(m->graph.gate, NB, NESTI_F16), tower_bytes(m->graph.gate, cascade_cap(NB), m->dtype))
+                        : tower_bytes(m->graph.gate, NB, m->dtype);
   for (const Tower& e : m->graph.experts) t = std::max(t, tower_bytes(e, NB, m->dtype));
   return t;
 }
 
 struct WsLayout {
-  size_t x0, probs, expert, counts, lists, tower, total;
+  size_t x0, probs, expert, counts, lists, keep, flags, fcounts, tower, total;
 };
 WsLayout ws_layout(const nesti_model* m, int NB) {
   WsLayout L;
@@ -794,15 +866,55 @@ WsLayout ws_layout(const nesti_model* m, int NB) {
   L.expert = o; o += align_up((size_t)NB * 4, 256);
   L.counts = o; o += 256;
   L.lists = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
+  L.keep = L.flags = L.fcounts = o;
+  if (m->cascade) {   // the f16 gate's logits, the flag list, [flag count | per-round counts]
+    L.keep = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
+    L.flags = o; o += align_up((size_t)NB * 4, 256);
+    L.fcounts = o; o += 512;
+  }
   L.tower = o; o += max_tower_bytes(m, NB);
   L.total = o;
   return L;
+}
+
+// NESTI_F16X3C (include/nesti_hip.h): the gating net in plain f16 over the batch, then in f16x3 over the rows whose f16
+// top-2 margin is below tau (gathered through the flag list like a routed expert gathers its rows), `cap` rows per round;
+// the routing lists are built from the final arg-max.  ws = the forward workspace (ws_layout), capacity NB >= B.
+int gate_cascade(const nesti_model* m, const void* X0, int B, unsigned char* ws, const WsLayout& L, int NB, float* probs,
+                 int32_t* expert, int32_t* counts, int32_t* lists, hipStream_t stream) {
+  const int E = m->graph.cfg.n_experts;
+  unsigned char* tower_ws = ws + L.tower;
+  const size_t tower_bytes_ = L.total - L.tower;
+  float* keep = (float*)(ws + L.keep);
+  int32_t* flag_list = (int32_t*)(ws + L.flags);
+  int32_t* flag_count = (int32_t*)(ws + L.fcounts);
+  int32_t* round_counts = flag_count + 8;
+  const int lstride = m->graph.gate.bufs[m->graph.gate.out_buf].C;
+  float* logits = nullptr;
+  RunCtx fast{m, B, nullptr, nullptr, stream, /*fast=*/true};
+  prof_phase(NESTI_PHASE_GATE);
+  if (run_tower(fast, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
+  prof_phase(NESTI_PHASE_RECHECK);
+  const int cap = std::min(cascade_cap(NB), B), rounds = (B + cap - 1) / cap;
+  if (launch_gate_flag(logits, lstride, B, E, m->tau, probs, expert, keep, flag_count, flag_list, cap, rounds, round_counts,
+                       m->cstat, stream))
+    return 1;
+  for (int r = 0; r < rounds; ++r) {
+    RunCtx exact{m, cap, round_counts + r, flag_list + (size_t)r * cap, stream};
+    if (run_tower(exact, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
+    if (launch_gate_recheck(logits, lstride, flag_list + (size_t)r * cap, round_counts + r, cap, E, keep, probs, expert,
+                            m->cstat, stream))
+      return 1;
+  }
+  if (counts) return launch_route(expert, B, E, counts, lists, stream);
+  return 0;
 }
 
 int gate_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_ws, size_t tower_bytes_,
               float* probs, int32_t* expert, int32_t* counts, int32_t* lists, hipStream_t stream) {
   RunCtx rc{m, B, nullptr, nullptr, stream};
   float* logits = nullptr;
+  prof_phase(NESTI_PHASE_GATE);
   if (run_tower(rc, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
   const int lstride = m->graph.gate.bufs[m->graph.gate.out_buf].C;
   if (m->graph.cfg.arch == NESTI_ARCH_SWITCH)   // noise_est < 0.015 -> small, else large (models/ms_sw_n_est.py:80-82)
@@ -813,6 +925,7 @@ int gate_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_
 int experts_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_ws, size_t tower_bytes_,
                  const int32_t* counts, const int32_t* lists, float* normals, hipStream_t stream) {
   const int E = m->graph.cfg.n_experts;
+  prof_phase(NESTI_PHASE_EXPERTS);
   for (int e = 0; e < E; ++e) {
     const Tower& T = m->graph.experts[e];
     float* out = nullptr;
@@ -911,8 +1024,14 @@ int nesti_model_describe(const nesti_config_t* cfg, int* n_tensors, nesti_tensor
 int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors, int n_tensors, int dtype,
                        nesti_model_t** out) {
   if (!cfg || !tensors || !out) NESTI_FAIL("nesti_model_create: null argument");
-  if (dtype != NESTI_F32 && dtype != NESTI_BF16 && dtype != NESTI_F16 && dtype != NESTI_BF16X3 && dtype != NESTI_F16X3) NESTI_FAIL("nesti_model_create: bad dtype");
+  if (dtype != NESTI_F32 && dtype != NESTI_BF16 && dtype != NESTI_F16 && dtype != NESTI_BF16X3 && dtype != NESTI_F16X3 &&
+      dtype != NESTI_F16X3C)
+    NESTI_FAIL("nesti_model_create: bad dtype");
+  if (dtype == NESTI_F16X3C && cfg->arch != NESTI_ARCH_EXPERTS)
+    NESTI_FAIL("nesti_model_create: NESTI_F16X3C is the two-stage gate of experts_n_est; use NESTI_F16X3 for the other models");
   std::unique_ptr<nesti_model> m(new nesti_model());
+  m->cascade = dtype == NESTI_F16X3C;
+  dtype = main_dtype(dtype);
   m->dtype = dtype;
   if (build_graph(cfg, &m->graph)) return 1;
   TensorTable tt;
@@ -920,12 +1039,50 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
   m->packed.resize(m->graph.layers.size());
   for (size_t i = 0; i < m->graph.layers.size(); ++i)
     if (pack_layer(m->graph.layers[i], tt, dtype, &m->packed[i])) return 1;
+  if (m->cascade) {
+    m->packed_fast.resize(m->graph.layers.size());
+    for (const Op& op : m->graph.gate.ops)
+      if (op.kind == Op::CONV && pack_layer(m->graph.layers[op.layer], tt, NESTI_F16, &m->packed_fast[op.layer])) return 1;
+    NESTI_CHECK_HIP(hipMalloc((void**)&m->cstat, 64));
+    NESTI_CHECK_HIP(hipMemset(m->cstat, 0, 64));
+  }
   NESTI_CHECK_HIP(hipDeviceSynchronize());
   *out = m.release();
   return 0;
 }
 
 void nesti_model_destroy(nesti_model_t* m) { delete m; }
+
+int nesti_model_set_gate_margin(nesti_model_t* m, float tau) {
+  if (!m || !m->cascade) NESTI_FAIL("nesti_model_set_gate_margin: not a NESTI_F16X3C model");
+  if (!(tau >= 0.f)) NESTI_FAIL("nesti_model_set_gate_margin: tau must be >= 0");
+  m->tau = tau;
+  return 0;
+}
+
+int nesti_model_cascade_stats(const nesti_model_t* m, nesti_cascade_stats_t* out, int reset, void* stream) {
+  if (!m || !m->cascade || !out) NESTI_FAIL("nesti_model_cascade_stats: not a NESTI_F16X3C model");
+  unsigned long long h[8];
+  NESTI_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  NESTI_CHECK_HIP(hipMemcpy(h, m->cstat, sizeof(h), hipMemcpyDeviceToHost));
+  if (reset) NESTI_CHECK_HIP(hipMemset(m->cstat, 0, 64));
+  out->queries = h[0]; out->rechecked = h[1]; out->changed = h[2];
+  const uint32_t bits = (uint32_t)h[3];
+  memcpy(&out->max_margin_err, &bits, 4);
+  out->tau = m->tau;
+  memcpy(&out->sum_sq_pair_err, &h[4], 8);
+  out->pairs = h[5];
+  return 0;
+}
+
+size_t nesti_tower_workspace_bytes(const nesti_config_t* cfg, int dtype, int tower, int batch) {
+  if (!cfg || batch <= 0) return 0;
+  Graph g;
+  if (build_graph(cfg, &g)) return 0;
+  if (tower < -1 || tower >= (int)g.experts.size()) return 0;
+  const int dt = tower < 0 && dtype == NESTI_F16X3C ? NESTI_F16 : main_dtype(dtype);
+  return tower_bytes(tower < 0 ? g.gate : g.experts[tower], batch, dt);
+}
 
 size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch) {
   if (!m || max_batch <= 0) return 0;
@@ -957,6 +1114,9 @@ int nesti_gate_forward(const nesti_model_t* m, const void* mups_dev, int B, void
   if (L.total > ws_bytes) NESTI_FAIL("nesti_gate_forward: workspace too small (see nesti_workspace_bytes)");
   unsigned char* ws = (unsigned char*)ws_dev;
   hipStream_t st = (hipStream_t)stream;
+  if (m->cascade)
+    return gate_cascade(m, mups_dev, B, ws, L, B, probs_out_dev, expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert),
+                        nullptr, nullptr, st);
   return gate_impl(m, mups_dev, B, ws + L.tower, L.total - L.tower, probs_out_dev, expert_out_dev, nullptr,
                    nullptr, st);
 }
@@ -981,7 +1141,7 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
 }
 
 // gate -> routing -> experts on a MuPS tensor X0 that already sits in the workspace
-static int forward_tail(const nesti_model_t* m, const void* X0, int B, unsigned char* ws, const WsLayout& L,
+static int forward_tail(const nesti_model_t* m, const void* X0, int B, int NB, unsigned char* ws, const WsLayout& L,
                         float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, hipStream_t st) {
   if (m->graph.cfg.arch == NESTI_ARCH_SINGLE || m->graph.cfg.arch == NESTI_ARCH_MULTI)   // single-tower ablations: the tower's output IS n_pred (test_n_est.py:136-141)
     return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, nullptr, nullptr, normals_out_dev, st);
@@ -989,7 +1149,9 @@ static int forward_tail(const nesti_model_t* m, const void* X0, int B, unsigned 
   int32_t* expert = expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert);
   int32_t* counts = (int32_t*)(ws + L.counts);
   int32_t* lists = (int32_t*)(ws + L.lists);
-  if (gate_impl(m, X0, B, ws + L.tower, L.total - L.tower, probs, expert, counts, lists, st)) return 1;
+  if (m->cascade ? gate_cascade(m, X0, B, ws, L, NB, probs, expert, counts, lists, st)
+                 : gate_impl(m, X0, B, ws + L.tower, L.total - L.tower, probs, expert, counts, lists, st))
+    return 1;
   return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
 }
 
@@ -1007,7 +1169,7 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
                               /*embed4=*/m->graph.cfg.grid_n == 3, st);
   prof_end(NESTI_PROF_MUPS, tok, st);
   if (rcm) return 1;
-  return forward_tail(m, X0, B, ws, L, normals_out_dev, expert_out_dev, probs_out_dev, st);
+  return forward_tail(m, X0, B, B, ws, L, normals_out_dev, expert_out_dev, probs_out_dev, st);
 }
 
 // ---- fused end-to-end entry: search grid + ball query + MuPS + gate + routed experts, batch by batch ---------------
@@ -1064,7 +1226,7 @@ int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N
                                           fwd_ws + L.x0, m->dtype, mups_stride(m), n_eff, st);
       prof_end(NESTI_PROF_MUPS, tok, st);
       if (rcf) return 1;
-      if (forward_tail(m, fwd_ws + L.x0, take, fwd_ws, L, n_out, e_out, p_out, st)) return 1;
+      if (forward_tail(m, fwd_ws + L.x0, take, batch, fwd_ws, L, n_out, e_out, p_out, st)) return 1;
     } else {
       if (nesti_patches_query(cfg, cloud_dev, N, qidx, take, r_abs, seed, query_row0 + done, points, n_eff, nullptr, nullptr,
                               grid_ws_dev, grid_ws_bytes, stream))
@@ -1127,7 +1289,7 @@ int nesti_estimate_normals_multi(const nesti_model_t* m, const nesti_shape_queri
       if (item_done >= it.n_queries) { ++item; item_done = 0; }
     }
     prof_end(NESTI_PROF_MUPS, tok, st);
-    if (forward_tail(m, X0, fill, fwd_ws, L, normals_out_dev + (size_t)done * 3, expert_out_dev ? expert_out_dev + done : nullptr,
+    if (forward_tail(m, X0, fill, batch, fwd_ws, L, normals_out_dev + (size_t)done * 3, expert_out_dev ? expert_out_dev + done : nullptr,
                      probs_out_dev ? probs_out_dev + (size_t)done * E : nullptr, st))
       return 1;
     done += fill;
@@ -1137,22 +1299,24 @@ int nesti_estimate_normals_multi(const nesti_model_t* m, const nesti_shape_queri
 
 int nesti_profile_enable(int on) {
   prof_collect();
-  for (int c = 0; c < NESTI_PROF_CATEGORIES; ++c) { g_prof.ms[c] = 0; g_prof.launches[c] = 0; }
+  for (int c = 0; c < kProfSlots; ++c) { g_prof.ms[c] = 0; g_prof.launches[c] = 0; }
   g_prof.on = on != 0;
+  g_prof.phase = NESTI_PHASE_INPUT;
   return 0;
 }
 
 int nesti_profile_read(double* ms, long long* launches) {
   prof_collect();   // synchronises on the recorded events
-  for (int c = 0; c < NESTI_PROF_CATEGORIES; ++c) {
+  for (int c = 0; c < kProfSlots; ++c) {
     if (ms) ms[c] = g_prof.ms[c];
     if (launches) launches[c] = g_prof.launches[c];
   }
   return 0;
 }
 
-int nesti_model_macs(const nesti_model_t* m, int tower, double* nominal, double* useful, double* issued) {
+int nesti_model_macs(const nesti_model_t* m, int tower, int kind, double* nominal, double* useful, double* issued) {
   if (!m) NESTI_FAIL("nesti_model_macs: null model");
+  if (kind < -1 || kind > NESTI_PROF_ONE_BY_ONE) NESTI_FAIL("nesti_model_macs: kind must be -1 or a conv category");
   const int E = m->graph.cfg.n_experts;
   if (tower < -1 || tower >= E) NESTI_FAIL("nesti_model_macs: tower must be -1 (gate) or an expert index");
   const Tower& T = tower < 0 ? m->graph.gate : m->graph.experts[tower];
@@ -1161,6 +1325,7 @@ int nesti_model_macs(const nesti_model_t* m, int tower, double* nominal, double*
     if (op.kind != Op::CONV) continue;
     const LayerDesc& d = m->graph.layers[op.layer];
     const PackedLayer& pl = m->packed[op.layer];
+    if (kind >= 0 && conv_category(d, pl) != kind) continue;
     const int S = d.s_real ? d.s_real : (1 << d.log2S), V = S * S * S, lo = (d.k - 1) / 2;
     long long valid = 0;   // sum over output voxels of the taps that land inside the volume
     for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)

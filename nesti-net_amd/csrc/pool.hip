@@ -164,6 +164,86 @@ __global__ void gate_finish_kernel(const float* __restrict__ logits, int lstride
   }
 }
 
+// ---- NESTI_F16X3C: the two-stage gate (include/nesti_hip.h) -----------------------------------------------------------
+// cstat: device counters of the model: [0] queries, [1] rechecked, [2] changed, [3] bits of max_margin_err (a float >= 0
+// orders like its bit pattern), [4] a double: sum of the squared pair errors, [5] the number of pairs in that sum.
+// Stage 1 (on the plain-f16 gate's logits): softmax + first-index arg-max like gate_finish_kernel; the logits are kept for
+// stage 2's error measurement and every row whose top-2 logit margin is below tau is appended to flag_list.
+__global__ void gate_flag_kernel(const float* __restrict__ logits, int lstride, int B, int E, float tau,
+                                 float* __restrict__ probs, int32_t* __restrict__ expert, float* __restrict__ keep,
+                                 int32_t* __restrict__ flag_count, int32_t* __restrict__ flag_list,
+                                 unsigned long long* __restrict__ cstat) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float l[NESTI_MAX_EXPERTS], mx = -INFINITY, second = -INFINITY;
+  for (int e = 0; e < E; ++e) {
+    l[e] = logits[(size_t)b * lstride + e];
+    keep[(size_t)b * NESTI_MAX_EXPERTS + e] = l[e];
+    if (l[e] > mx) { second = mx; mx = l[e]; } else second = fmaxf(second, l[e]);
+  }
+  const bool flag = !(mx - second >= tau);   // a NaN margin is rechecked too
+  float sum = 0.f;
+  for (int e = 0; e < E; ++e) { l[e] = expf(l[e] - mx); sum += l[e]; }
+  int best = 0;
+  float pb = -1.f;
+  for (int e = 0; e < E; ++e) {
+    const float pr = l[e] / sum;
+    if (probs) probs[(size_t)b * E + e] = pr;
+    if (pr > pb) { pb = pr; best = e; }
+  }
+  expert[b] = best;
+  if (flag) flag_list[atomicAdd(flag_count, 1)] = b;
+  // one counter update per wave
+  const unsigned long long fm = __ballot(flag), am = __ballot(true);
+  if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) {
+    atomicAdd(&cstat[0], (unsigned long long)__popcll(am));
+    if (fm) atomicAdd(&cstat[1], (unsigned long long)__popcll(fm));
+  }
+}
+
+// rows [r * cap, r * cap + cap) of the flag list are one recheck round (the f16x3 gate runs on `cap` rows at a time)
+__global__ void round_counts_kernel(const int32_t* __restrict__ flag_count, int cap, int n_rounds, int32_t* __restrict__ out) {
+  const int r = threadIdx.x;
+  if (r < n_rounds) out[r] = max(0, min(cap, *flag_count - r * cap));
+}
+
+// Stage 2 (on the f16x3 gate's logits of one round, compact rows j <-> query flag_list[j]): the final probabilities and
+// arg-max of those queries, and the f16 gate's error on the logit differences against its own arg-max.
+__global__ void gate_recheck_kernel(const float* __restrict__ logits, int lstride, const int32_t* __restrict__ flag_list,
+                                    const int32_t* __restrict__ count_ptr, int cap, int E, const float* __restrict__ keep,
+                                    float* __restrict__ probs, int32_t* __restrict__ expert,
+                                    unsigned long long* __restrict__ cstat) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= min(cap, *count_ptr)) return;
+  const int b = flag_list[j];
+  float l[NESTI_MAX_EXPERTS], mx = -INFINITY;
+  for (int e = 0; e < E; ++e) { l[e] = logits[(size_t)j * lstride + e]; mx = fmaxf(mx, l[e]); }
+  const int a = expert[b];                       // the f16 gate's arg-max
+  float err = 0.f, sq = 0.f;
+  for (int e = 0; e < E; ++e) {
+    const float d16 = keep[(size_t)b * NESTI_MAX_EXPERTS + a] - keep[(size_t)b * NESTI_MAX_EXPERTS + e];
+    const float pe = fabsf(d16 - (l[a] - l[e]));      // the f16 pass's error on the logit difference (a, e); 0 for e == a
+    err = fmaxf(err, pe);
+    sq += pe * pe;
+  }
+  float sum = 0.f;
+  for (int e = 0; e < E; ++e) { l[e] = expf(l[e] - mx); sum += l[e]; }
+  int best = 0;
+  float pb = -1.f;
+  for (int e = 0; e < E; ++e) {
+    const float pr = l[e] / sum;
+    if (probs) probs[(size_t)b * E + e] = pr;
+    if (pr > pb) { pb = pr; best = e; }
+  }
+  expert[b] = best;
+  if (best != a) atomicAdd(&cstat[2], 1ull);
+  if (err == err) {
+    atomicMax(&cstat[3], (unsigned long long)__float_as_uint(err));
+    atomicAdd(reinterpret_cast<double*>(&cstat[4]), (double)sq);
+    atomicAdd(&cstat[5], (unsigned long long)(E - 1));
+  }
+}
+
 // tf.where(noise_est < 0.015, n_est_small, n_est_large) as a routing decision (models/ms_sw_n_est.py:80-82)
 __global__ void switch_finish_kernel(const float* __restrict__ logits, int lstride, int B, float threshold,
                                      float* __restrict__ probs, int32_t* __restrict__ expert,
@@ -251,6 +331,28 @@ int launch_gate_finish(const float* logits, int lstride, int B, int E, float* pr
   if (counts) hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, stream, counts, E);
   hipLaunchKernelGGL(gate_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, E,
                      probs, expert, counts, lists);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gate_flag(const float* logits, int lstride, int B, int E, float tau, float* probs, int32_t* expert, float* keep,
+                     int32_t* flag_count, int32_t* flag_list, int cap, int n_rounds, int32_t* round_counts,
+                     unsigned long long* cstat, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (E > NESTI_MAX_EXPERTS || n_rounds > 64) NESTI_FAIL("gate_flag: too many experts / rounds");
+  hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, stream, flag_count, 1);
+  hipLaunchKernelGGL(gate_flag_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, E, tau, probs,
+                     expert, keep, flag_count, flag_list, cstat);
+  hipLaunchKernelGGL(round_counts_kernel, dim3(1), dim3(64), 0, stream, flag_count, cap, n_rounds, round_counts);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gate_recheck(const float* logits, int lstride, const int32_t* flag_list, const int32_t* count_ptr, int cap, int E,
+                        const float* keep, float* probs, int32_t* expert, unsigned long long* cstat, hipStream_t stream) {
+  if (cap <= 0) return 0;
+  hipLaunchKernelGGL(gate_recheck_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, logits, lstride, flag_list,
+                     count_ptr, cap, E, keep, probs, expert, cstat);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -45,7 +45,7 @@ def pack_results(normals, expert, probs, out):
 
 def unpack_results(buf, gated=True):
     if not gated:
-        return buf[:, 0:3].contiguous(), None, None
+        return buf[:, 0:3].clone(), None, None      # [.., 3] is the whole row here: contiguous() would alias the cached buffer
     return buf[:, 0:3].contiguous(), buf[:, 3].contiguous().view(torch.int32), buf[:, 4:].contiguous()
 
 

@@ -16,7 +16,8 @@ from . import _lib
 from .config import ARCH_MULTI, ARCH_SINGLE, DTYPES, NestiConfig
 
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16,
-             "bf16x3": torch.bfloat16, "f16x3": torch.float16}   # pair modes: 16-bit elements, three planes per 64-channel group
+             "bf16x3": torch.bfloat16, "f16x3": torch.float16,   # pair modes: 16-bit elements, three planes per 64-channel group
+             "f16x3c": torch.float16}                            # f16x3 with the two-stage gate (include/nesti_hip.h: NESTI_F16X3C)
 
 
 def get_3d_grid_gmm(subdivisions=(8, 8, 8), variance=0.0156):
@@ -68,7 +69,9 @@ class NestiNet:
     :mod:`.weights`).  ``dtype``: 'bf16' / 'f16' (MFMA 32x32x16, fp32 accumulate), 'f32' (exact-fp32 MFMA; the mode
     tied to the CPU oracle) or the pair modes 'f16x3' / 'bf16x3' (activations and weights as 16-bit hi + lo pairs, three
     MFMA products per multiply, a third of the 16-bit rate: f16x3 stays two orders of magnitude inside the reference's 1e-5
-    cosine tolerance of the f32 mode, bf16x3 is at its edge)."""
+    cosine tolerance of the f32 mode, bf16x3 is at its edge).  'f16x3c' is f16x3 with the two-stage gate: the gating net
+    runs in plain f16 first and only the queries whose f16 top-2 logit margin is below ``gate_margin`` are decided by the
+    f16x3 gating net (:meth:`set_gate_margin`, :meth:`cascade_stats`)."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", max_batch=1024):
         self.lib = _lib.load()
@@ -90,6 +93,7 @@ class NestiNet:
             _lib.check(self.lib.nesti_model_create(ctypes.byref(self._c), arr, len(names), DTYPES[dtype],
                                                    ctypes.byref(self._handle)), "nesti_model_create")
         self._keep = None
+        self.cascade = dtype == "f16x3c"
         self.mups_cstride = self.lib.nesti_model_mups_cstride(self._handle)
         self._ws = None
         self._ws_batch = 0
@@ -103,6 +107,23 @@ class NestiNet:
                 h.value = None
         except Exception:      # interpreter shutdown: modules may already be torn down
             pass
+
+    # -- two-stage gate (dtype 'f16x3c') -----------------------------------------------------
+    def set_gate_margin(self, tau):
+        """Queries whose f16 top-2 gate-logit margin is below ``tau`` are decided by the f16x3 gating net."""
+        _lib.check(self.lib.nesti_model_set_gate_margin(self._handle, float(tau)), "nesti_model_set_gate_margin")
+
+    def cascade_stats(self, reset=False, stream=None):
+        """Counters of the two-stage gate since the last reset (synchronises the stream): dict with queries, rechecked,
+        changed, max_margin_err (the f16 gate's largest error on a logit difference among the rechecked queries), sigma
+        (the standard deviation of that error over all rechecked (query, expert) pairs) and tau."""
+        st = _lib.CCascadeStats()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_model_cascade_stats(self._handle, ctypes.byref(st), int(bool(reset)), self._stream(stream)),
+                       "nesti_model_cascade_stats")
+        sigma = (st.sum_sq_pair_err / st.pairs) ** 0.5 if st.pairs else 0.0
+        return {"queries": int(st.queries), "rechecked": int(st.rechecked), "changed": int(st.changed),
+                "max_margin_err": float(st.max_margin_err), "sigma": float(sigma), "tau": float(st.tau)}
 
     # -- workspace -------------------------------------------------------------------------
     def reserve(self, batch):

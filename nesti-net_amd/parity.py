@@ -2,15 +2,23 @@
 
 The north star asks for the expert arg-max bit-exact and the normals within 1e-5 cosine of the
 reference's fp32 CPU result (``test_n_est_w_experts.py:150-152``, ``models/experts_n_est.py:174-177``).
-The exact-fp32 MFMA mode (``dtype='f32'``) is the mode tied to the CPU oracle (tests/test_gpu_net.py,
-tests/test_gpu_fixtures.py); a production dtype (f16 / bf16) is characterised against it on the full
-workload: arg-max match rate, every flip counted and classified by the reference's top-2 probability
-margin, and the distribution of 1 - cos between the normal vectors.
+The exact-fp32 MFMA mode (``dtype='f32'``) is the mode tied to the fp64 CPU oracle (tests/test_gpu_net.py,
+tests/test_gpu_fixtures.py: ~1.8k queries over six fixture clouds); a faster mode is characterised against it on the
+full workload: every arg-max difference is counted, and ``meets_north_star`` is the strict reading of the clause --
+
+* no arg-max difference at all, except where the fp32 reference's OWN top-2 probabilities are closer than
+  ``TIE_MARGIN`` = 2e-5: an fp32 evaluation in another summation order (the reference's Eigen convolutions, this
+  library's f32 MFMA mode, or the fp64 oracle, which the f32 mode matches to 6e-5 in probability) does not define the
+  arg-max of such a query, so it cannot be "bit-exact" against anything; these are reported as ``argmax_ties``;
+* 1 - cos <= 1e-5 on EVERY query whose arg-max agrees (a tie that resolved the other way returns another expert's normal
+  and is reported through ``max_incl_flips``).
+
+``strict_bit_exact_argmax`` is the even stricter boolean (zero differences, ties included).
 """
 import numpy as np
 
 COS_TOL = 1e-5            # north star: cosine tolerance on the normal vectors
-MARGIN_FLAG = 2e-3        # an arg-max flip is "margin-flagged" when the fp32 run's top-2 probabilities are closer than this
+TIE_MARGIN = 2e-5         # the fp32 reference's own top-2 probabilities closer than this: the arg-max is not defined by fp32 arithmetic
 
 
 def _cos(a, b):
@@ -19,13 +27,15 @@ def _cos(a, b):
     return (a * b).sum(-1) / den
 
 
-def compare(test, ref, margin_flag=MARGIN_FLAG, cos_tol=COS_TOL):
+def compare(test, ref, tie_margin=TIE_MARGIN, cos_tol=COS_TOL):
     """``test`` / ``ref``: (normals [n,3], expert [n] or None, probs [n,E] or None) as numpy arrays, ``ref`` from the
     exact-fp32 mode.  Returns a JSON-serialisable dict."""
     n_t, e_t, p_t = test
     n_r, e_r, p_r = ref
     n = len(n_r)
     out = {"queries": int(n), "reference": "same library, exact-fp32 MFMA mode (dtype f32), same queries",
+           "oracle_queries": "the f32 mode itself is held to the fp64 CPU oracle on ~1.8k queries of six fixture clouds "
+                             "(tests/test_gpu_fixtures.py); all weights are synthetic (no checkpoint ships with the reference)",
            "cos_tol": cos_tol}
     omc = 1.0 - _cos(n_t, n_r)
     if e_r is None:                       # single-tower models: no gate
@@ -38,11 +48,11 @@ def compare(test, ref, margin_flag=MARGIN_FLAG, cos_tol=COS_TOL):
         out.update({
             "argmax_match_rate": float(same.mean()) if n else 1.0,
             "argmax_flips": int(flips.sum()),
-            "margin_flag": margin_flag,
-            "flips_margin_flagged": int((flips & (margin < margin_flag)).sum()),
-            "flips_outside_margin": int((flips & (margin >= margin_flag)).sum()),
+            "tie_margin": tie_margin,
+            "argmax_ties": int((flips & (margin < tie_margin)).sum()),
+            "flips_outside_margin": int((flips & (margin >= tie_margin)).sum()),
             "flip_margin_max": float(margin[flips].max()) if flips.any() else 0.0,
-            "queries_within_margin": int((margin < margin_flag).sum()),
+            "queries_within_margin": int((margin < tie_margin).sum()),
             "prob_abs_err_max": float(np.abs(np.asarray(p_t, np.float64) - np.asarray(p_r, np.float64)).max()) if n else 0.0,
         })
     m = omc[same]
@@ -51,4 +61,5 @@ def compare(test, ref, margin_flag=MARGIN_FLAG, cos_tol=COS_TOL):
                             "over": "queries whose arg-max agrees (a flipped query is a different expert's normal)",
                             "max_incl_flips": float(omc.max()) if n else 0.0}
     out["meets_north_star"] = bool(out.get("flips_outside_margin", 0) == 0 and out["one_minus_cos"]["max"] <= cos_tol)
+    out["strict_bit_exact_argmax"] = bool(out.get("argmax_flips", 0) == 0)
     return out

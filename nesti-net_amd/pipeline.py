@@ -19,7 +19,7 @@ class NormalEstimator:
     hipGraph once and replays it; only worthwhile for small batches where launch gaps matter."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", batch=4096, seed=3627473,
-                 use_graph=False, n_streams=1):
+                 use_graph=False, n_streams=1, gate_margin=None):
         self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
         self.use_graph = bool(use_graph)
         # n_streams > 1: consecutive batches alternate between HIP streams (own staging buffers and scratch
@@ -29,6 +29,8 @@ class NormalEstimator:
         # the patch staging buffers and the forward workspace; the graph / multi-stream modes drive the batches from here
         self._fused = not self.use_graph and self.n_streams == 1
         self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=1 if self._fused else self.batch)
+        if gate_margin is not None:                       # dtype 'f16x3c' only (calibrate.calibrate_gate_margin picks one)
+            self.net.set_gate_margin(gate_margin)
         S, P, E = cfg.n_scales, cfg.num_point, max(1, cfg.n_gate_out)
         if self._fused:
             nbytes = self.net.lib.nesti_estimate_workspace_bytes(self.net._handle, self.batch)

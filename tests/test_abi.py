@@ -150,7 +150,8 @@ def test_python_enums_follow_the_header():
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         for name, val in re.findall(r"(NESTI_[A-Z0-9_]+)\s*=\s*(\d+)", body):
             enums[name] = int(val)
-    want = {"f32": "NESTI_F32", "bf16": "NESTI_BF16", "f16": "NESTI_F16", "bf16x3": "NESTI_BF16X3", "f16x3": "NESTI_F16X3"}
+    want = {"f32": "NESTI_F32", "bf16": "NESTI_BF16", "f16": "NESTI_F16", "bf16x3": "NESTI_BF16X3", "f16x3": "NESTI_F16X3",
+            "f16x3c": "NESTI_F16X3C"}
     assert set(config.DTYPES) == set(want)
     for k, name in want.items():
         assert config.DTYPES[k] == enums[name], k

@@ -1,0 +1,130 @@
+"""dtype 'f16x3c' (NESTI_F16X3C, include/nesti_hip.h): f16x3 with the two-stage gate -- the gating net
+(models/experts_n_est.py:155-179) runs in plain f16 as a filter and only the queries whose f16 top-2 logit margin is below
+the gate margin tau are decided by the f16x3 gating net; the experts always run in f16x3.
+
+What must hold, whatever tau is: the normals of a query are the f16x3 normals of the expert it was routed to; with
+tau = inf every output equals the f16x3 mode bit for bit; with tau = 0 the arg-max is the plain f16 gate's; with the
+calibrated tau the arg-max equals the f16x3 arg-max on every query and the f16 gate's measured error on a logit difference
+(nesti_model_cascade_stats) stays below tau / 2."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B = 6000      # > 4096: the recheck runs in four rounds of 1536 rows (model.hip: cascade_cap)
+
+
+@pytest.fixture(scope="module")
+def case(gpu_device):
+    from nesti_net_amd import synth, weights
+    from nesti_net_amd.calibrate import calibrate_gate
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from nesti_net_amd.provider import CloudPatches
+    cfg = NestiConfig()
+    pts = synth.make_cloud("ellipsoid", n=100000, seed=1234)[0]
+    q = np.arange(5, 100000, 100000 // B)[:B]
+    cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
+    points, n_eff = cp.build(0, B)
+    W = calibrate_gate(cfg, weights.synthetic_weights(cfg), points[:512], n_eff[:512], device=gpu_device)
+    x3 = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=B)
+    ref = [t.clone() for t in x3(points, n_eff)]
+    n_all = x3.experts(x3.mups(points, n_eff), None).clone()          # [E, B, 3]: every expert's f16x3 normal of every query
+    f16 = NestiNet(cfg, W, dtype="f16", device=gpu_device, max_batch=B)
+    p16, e16 = [t.clone() for t in f16.gate(f16.mups(points, n_eff))]
+    torch.cuda.synchronize()
+    del x3, f16
+    torch.cuda.empty_cache()
+    return cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16
+
+
+def test_tau_infinite_equals_f16x3_bitwise_and_counts_every_query(case, gpu_device):
+    from nesti_net_amd.model import NestiNet
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
+    net.set_gate_margin(1e30)
+    out = net(points, n_eff)
+    st = net.cascade_stats(reset=True)
+    for a, b in zip(out, ref):
+        assert torch.equal(a, b)
+    assert st["queries"] == B and st["rechecked"] == B
+    assert st["changed"] == int((e16 != ref[1]).sum().item())          # what the f16 gate alone would have got wrong
+    assert 0 < st["max_margin_err"] < 1.0
+    # .gate() / .experts() (the reference-shaped pieces) go through the same two stages
+    mups = net.mups(points, n_eff)
+    probs, expert = net.gate(mups)
+    assert torch.equal(probs, ref[2]) and torch.equal(expert, ref[1])
+    assert torch.equal(net.experts(mups, expert), ref[0])
+    assert net.cascade_stats()["queries"] == B                          # the reset above took effect, this call counted again
+
+
+def test_tau_zero_keeps_the_f16_gate_and_routes_f16x3_experts(case, gpu_device):
+    from nesti_net_amd.model import NestiNet
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
+    net.set_gate_margin(0.0)
+    normals, expert, probs = net(points, n_eff)
+    st = net.cascade_stats()
+    assert st["rechecked"] == 0 and st["changed"] == 0 and st["max_margin_err"] == 0.0
+    assert torch.equal(expert, e16) and torch.equal(probs, p16)        # the filter pass IS the plain f16 gate (hi plane of the pair MuPS)
+    pick = n_all[expert.long(), torch.arange(B, device=gpu_device)]
+    assert torch.equal(normals, pick)                                   # f16x3 normals of whatever expert was chosen
+
+
+def test_calibrated_margin_reproduces_the_f16x3_decisions(case, gpu_device):
+    from nesti_net_amd.calibrate import calibrate_gate_margin
+    from nesti_net_amd.model import NestiNet
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
+    tau = calibrate_gate_margin(net, points[:1024], n_eff[:1024])
+    assert 0 < tau < 2.0
+    normals, expert, probs = net(points, n_eff)
+    st = net.cascade_stats()
+    print("tau", tau, st, "f16 gate flips", int((e16 != ref[1]).sum().item()))
+    assert st["queries"] == B and 0 < st["rechecked"] < B // 2          # a filter, not a second full pass
+    assert st["max_margin_err"] <= tau / 2                              # the bound tau rests on, re-measured on this batch
+    assert torch.equal(expert, ref[1]) and torch.equal(normals, ref[0])
+    # probabilities: f16x3's on the rechecked rows, the f16 gate's elsewhere
+    same = (probs == ref[2]).all(dim=1)
+    assert int(same.sum().item()) >= st["rechecked"]
+    assert torch.equal(probs[~same], p16[~same])
+
+
+def test_product_path_batches_graph_and_stream_modes_agree(case, gpu_device):
+    """nesti_estimate_normals with a ragged tail, the per-batch Python loop, a captured hipGraph and run_many: the same
+    bits (each query's result depends on neither its batch nor its position in the flag list)."""
+    from nesti_net_amd.pipeline import NormalEstimator
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    sub = q[:2500]
+    outs = []
+    for kw in ({"batch": 2500}, {"batch": 1000}, {"batch": 1024, "use_graph": True}, {"batch": 900, "n_streams": 2}):
+        est = NormalEstimator(cfg, W, dtype="f16x3c", device=gpu_device, gate_margin=0.3, **kw)
+        outs.append(est.estimate(pts, pidx=sub))
+        if kw == {"batch": 1000}:
+            cloud = est.prepare(pts, pidx=sub)
+            many = est.run_many([(cloud, 0, 700), (cloud, 700, 1800)])
+            torch.cuda.synchronize()
+            for k in range(3):
+                assert np.array_equal(np.concatenate([many[0][k].cpu().numpy(), many[1][k].cpu().numpy()]), outs[0][k])
+        del est
+        torch.cuda.empty_cache()
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert np.array_equal(a, b)
+    assert np.array_equal(outs[0][1], ref[1][:2500].cpu().numpy())
+
+
+def test_cascade_is_for_the_gated_model_only(gpu_device):
+    from nesti_net_amd import _lib, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    cfg = NestiConfig.for_model("ss_norm_est")
+    with pytest.raises(_lib.NestiError, match="NESTI_F16X3C"):
+        NestiNet(cfg, weights.synthetic_weights(cfg), dtype="f16x3c", device=gpu_device, max_batch=4)
+    cfg = NestiConfig()
+    net = NestiNet(cfg, weights.synthetic_weights(cfg), dtype="f16x3", device=gpu_device, max_batch=4)
+    with pytest.raises(_lib.NestiError, match="not a NESTI_F16X3C model"):
+        net.set_gate_margin(0.1)
+    with pytest.raises(_lib.NestiError):
+        net.cascade_stats()

@@ -7,7 +7,7 @@ from conftest import golden_patch_files, load_golden_patches
 
 pytestmark = pytest.mark.gpu
 
-TOL_F32 = 2e-5     # abs, on L2-normalised channels (|v| <= 1); fp32 kernel vs fp64 restatement
+TOL_F32 = 5e-6     # abs, on L2-normalised channels (|v| <= 1); fp32 kernel vs fp64 restatement
 TOL_BF16 = 6e-3    # bf16 storage: 2^-8 relative on |v| <= 1
 
 

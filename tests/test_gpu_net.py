@@ -58,7 +58,7 @@ def test_f32_gate_and_routing_match_oracle(setup, oracle_out, net_f32, gpu_devic
     p = torch.as_tensor(pts, device=gpu_device)
     n = torch.as_tensor(n_eff, device=gpu_device)
     mups = net_f32.mups(p, n)
-    assert np.abs(mups[..., :60].cpu().numpy() - mups_o).max() < 2e-5
+    assert np.abs(mups[..., :60].cpu().numpy() - mups_o).max() < 5e-6
     probs, expert = net_f32.gate(mups)
     torch.cuda.synchronize()
     pe = np.abs(probs.cpu().numpy() - top1["probs"].numpy()).max()
@@ -307,7 +307,7 @@ def test_3_gaussian_grid_model_matches_oracle(gpu_device):
     # MuPS: dense [B,3,3,3,60] through the public entry point, and the towers' 4^3-embedded layout
     dense = mups_forward(cfg, p_d, n_d, out_dtype="f32").cpu().numpy()
     assert dense.shape == (B, 3, 3, 3, 60)
-    assert np.abs(dense - mups_o).max() < 2e-5
+    assert np.abs(dense - mups_o).max() < 5e-6
     net = NestiNet(cfg, W, dtype="f32", device=gpu_device, max_batch=B)
     emb = net.mups(p_d, n_d)
     assert emb.shape == (B, 4, 4, 4, 64)
@@ -385,7 +385,7 @@ def test_limits_four_scales_eight_experts(gpu_device):
     assert net.mups_cstride == 128
     mups = net.mups(p_d, n_d)
     mups_o = mups_ref.mups_assemble(o_pts, o_neff, 4)
-    assert np.abs(mups.cpu().numpy()[..., :80] - mups_o).max() < 2e-5 and not mups.cpu().numpy()[..., 80:].any()
+    assert np.abs(mups.cpu().numpy()[..., :80] - mups_o).max() < 5e-6 and not mups.cpu().numpy()[..., 80:].any()
     ref = net_ref.moe_forward(mups_o, W, expert_dict=cfg.expert_dict, dtype=torch.float64)
     probs, expert = net.gate(mups)
     assert np.abs(probs.cpu().numpy() - ref["probs"].numpy()).max() < PROB_TOL_F32

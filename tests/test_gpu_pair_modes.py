@@ -53,7 +53,7 @@ def test_pair_mode_matches_the_fp64_oracle_on_golden_patches(mode, gpu_device):
     assert mups.shape == (16, 8, 8, 8, 192) and mups.dtype == TORCH_DT[mode]
     m = mups.float().cpu().numpy()
     assert np.array_equal(m[..., 0:64], m[..., 128:192])
-    assert np.abs(m[..., 0:60] + m[..., 64:124] - mups_o).max() < 2e-5
+    assert np.abs(m[..., 0:60] + m[..., 64:124] - mups_o).max() < (2e-5 if mode == "bf16x3" else 5e-6)
     assert not m[..., 60:64].any() and not m[..., 124:128].any()
     normals, expert, probs = net(p, n)
     torch.cuda.synchronize()
@@ -66,7 +66,7 @@ def test_pair_mode_matches_the_fp64_oracle_on_golden_patches(mode, gpu_device):
     ca = _cos(n_est, full["n_est"].numpy())
     print(mode, "vs oracle: prob err", pe, "agree", agree.mean(), "1-cos max", (1 - c).max(), "all experts", (1 - ca).max())
     assert pe < (1e-3 if mode == "bf16x3" else 1e-4)  # 2^-17 operands on O(10) logits; f16 pairs: like the fp32 mode
-    assert np.all(agree | (margin < (2e-3 if mode == "bf16x3" else 2e-4)))
+    assert np.all(agree | (margin < (2e-3 if mode == "bf16x3" else 2e-5)))
     assert np.all(1 - c < COS_TOL) and np.all(1 - ca < COS_TOL)
     if mode == "f16x3":
         assert (1 - c).max() < 1e-7 and (1 - ca).max() < 1e-7
