@@ -262,6 +262,10 @@ int nesti_write_text_f32(const char* path, const float* data, int64_t rows, int 
 /* np.savetxt(path, a.astype(int), fmt='%i') (test_n_est_w_experts.py:185-186). */
 int nesti_write_text_i32(const char* path, const int32_t* data, int64_t rows);
 
+/* CRC-32C of n host bytes continuing from `crc` (0 to start): the checksum of TensorFlow's tensor bundle, verified on
+ * restore (test_n_est_w_experts.py:98-105 -> tf_ckpt.read_bundle).  Stored masked: ((crc >> 15) | (crc << 17)) + 0xa282ead8. */
+uint32_t nesti_crc32c(const void* data, size_t n, uint32_t crc);
+
 /* ---- measurement support (bench.py's roofline leg; no reference counterpart) ------------
  * nesti_profile_enable(1) makes every kernel launch of the forward path record a pair of
  * hipEvents on its stream; nesti_profile_read() synchronises on them and returns, per
@@ -284,8 +288,9 @@ int nesti_profile_read(double* ms /*[NESTI_PROF_PHASES * NESTI_PROF_CATEGORIES]*
  * category `kind` (NESTI_PROF_CONV8_K5 .. NESTI_PROF_ONE_BY_ONE; -1: all of them):
  *   nominal = dense conv as TensorFlow executes it (zero-padding taps included),
  *   useful  = taps that land inside the volume only (the algorithmic figure),
- *   issued  = what the MFMA kernels issue for ONE 16-bit product (channel padding and unskipped padding taps included;
- *             the pair modes issue three such products per multiply). */
+ *   issued  = what the MFMA kernels issue for ONE 16-bit product: channel padding included, padding taps included except
+ *             the MFMA tiles the kernels skip (x-lines whose y + dy or z + dz leaves the volume, at 8^3 and 4^3); the
+ *             pair modes issue three such products per multiply. */
 int nesti_model_macs(const nesti_model_t* m, int tower, int kind, double* nominal, double* useful,
                      double* issued);
 

@@ -32,9 +32,16 @@ def build_parser():
     p.add_argument("--batch_size", type=int, default=128, help="Batch size [default: 128]; the library batches internally")
     p.add_argument("--testset", type=str, default="testset_temp.txt", help="test set file name, default testset_temp.txt")
     # extensions (not in the reference)
-    p.add_argument("--dtype", default="f16", choices=["bf16", "f16", "f16x3", "bf16x3", "f32"],
-                   help="MFMA precision mode: f16 (default) / bf16 are the fast modes (parity distributions in DESIGN.md), f16x3 "
-                        "(hi + lo pairs) meets the 1e-5 cosine tolerance at a third of the rate, f32 is the exact-fp32 MFMA mode")
+    p.add_argument("--dtype", default="auto", choices=["auto", "f16x3c", "f16x3", "bf16x3", "f16", "bf16", "f32"],
+                   help="MFMA precision mode.  auto (default): the modes that keep the output files within the reference's "
+                        "tolerance (arg-max exact up to fp32 ties, 1e-5 cosine) -- f16x3c for experts_n_est (f16 hi + lo pairs "
+                        "behind the two-stage gate, its margin calibrated on the first shape), f16x3 for the other models; "
+                        "f16 / bf16: plain 16-bit, ~1.9x faster, hundreds of arg-max flips per 100k points (DESIGN.md 2); "
+                        "f32: the exact-fp32 MFMA mode")
+    p.add_argument("--subsample", default="hash", choices=["hash", "reference"],
+                   help="how balls with more than num_point points are thinned: hash = on the GPU, order-independent (default); "
+                        "reference = exactly like the reference (scipy cKDTree order + its RandomState stream, on the host, "
+                        "~1 ms per patch) for row-by-row diffs against a real reference run")
     p.add_argument("--synthetic_weights", action="store_true", help="use seeded synthetic weights if model.nstw is absent")
     return p
 
@@ -77,13 +84,23 @@ def main(argv=None):
     if cfg.arch != arch:
         raise SystemExit("--model %s does not match the trained model in %s" % (FLAGS.model, results_path))
     device = "cuda:%d" % FLAGS.gpu
-    est = NormalEstimator(cfg, W, dtype=FLAGS.dtype, device=device, batch=max(FLAGS.batch_size, 4096), n_streams=2)
+    dtype = FLAGS.dtype if FLAGS.dtype != "auto" else ("f16x3c" if arch == ARCH_EXPERTS else "f16x3")
+    if dtype == "f16x3c" and arch != ARCH_EXPERTS:
+        raise SystemExit("--dtype f16x3c is the two-stage gate of experts_n_est; use f16x3 for --model %s" % FLAGS.model)
+    est = NormalEstimator(cfg, W, dtype=dtype, device=device, batch=max(FLAGS.batch_size, 4096), n_streams=2,
+                          subsample=FLAGS.subsample)
     printout("Model restored.")
 
     dataset = PointcloudPatchDataset(pc_path, FLAGS.testset, cfg, seed=3627473, sparse_patches=FLAGS.sparse_patches,
                                      device=device)
     for ind, name in enumerate(dataset.shape_names):
         cloud = dataset.get_shape(ind)
+        if dtype == "f16x3c" and ind == 0:
+            # the gate margin, from up to 1024 queries of the first shape (calibrate.calibrate_gate_margin)
+            from .calibrate import calibrate_gate_margin
+            sp, sn = cloud.build(0, min(1024, cloud.patch_count))
+            printout("gate margin tau = %.4g" % calibrate_gate_margin(est.net, sp, sn))
+            del sp, sn
         normals, expert, probs = est.run(cloud)
         torch.cuda.synchronize()
         # byte-identical to the reference's np.savetxt calls (test_n_est_w_experts.py:182-188), ~6x faster
@@ -94,6 +111,10 @@ def main(argv=None):
         textio.write_i32(os.path.join(output_dir, name + ".experts"), expert.cpu().numpy())
         textio.write_f32(os.path.join(output_dir, name + ".experts_probs"), probs.cpu().numpy())
         printout("saved experts for " + name)
+    if dtype == "f16x3c":
+        st = est.net.cascade_stats()
+        printout("two-stage gate: %d of %d queries decided by the f16x3 gate, f16 gate error on a logit difference <= %.4g "
+                 "(tau %.4g)" % (st["rechecked"], st["queries"], st["max_margin_err"], st["tau"]))
     flog.close()
     return 0
 

@@ -1336,7 +1336,16 @@ int nesti_model_macs(const nesti_model_t* m, int tower, int kind, double* nomina
     const int parts = d.scope2.empty() ? 1 : 2;
     nom += (double)parts * V * d.k * d.k * d.k * d.cin * d.cout;
     use += (double)parts * valid * d.cin * d.cout;
-    iss += (double)(1 << (3 * d.log2S)) * pl.n_taps * d.Cin_p * d.Cout_p;
+    // MFMA tiles the kernels issue: conv8_kernel (8^3) and the remapped conv_igemm_kernel layout at 4^3 hold one x-line
+    // (y, z) per 32-row tile and skip it when y + dy or z + dz leaves the volume; elsewhere every kept tap is issued in full
+    double tap_sum = pl.n_taps;
+    const int Si = 1 << d.log2S;
+    if (pl.n_taps > 1 && (pl.kind == 1 || (d.log2S == 2 && conv_remap(d.k, d.log2S, pl.n_taps)))) {
+      tap_sum = 0;
+      for (int t = 0; t < pl.n_taps; ++t)
+        tap_sum += (double)std::max(0, S - abs(pl.tap[t][0])) * std::max(0, S - abs(pl.tap[t][1])) / ((double)Si * Si);
+    }
+    iss += (double)(1 << (3 * d.log2S)) * tap_sum * d.Cin_p * d.Cout_p;
   }
   if (nominal) *nominal = nom;
   if (useful) *useful = use;

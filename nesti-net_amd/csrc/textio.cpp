@@ -19,7 +19,41 @@ namespace nesti { void set_error(const std::string& msg); }
 
 static int fail(const std::string& m) { nesti::set_error(m); return 1; }
 
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slice-by-8 tables built once
+static uint32_t g_crc_tab[8][256];
+static void crc_init() {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+    g_crc_tab[0][i] = c;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int t = 1; t < 8; ++t) g_crc_tab[t][i] = (g_crc_tab[t - 1][i] >> 8) ^ g_crc_tab[0][g_crc_tab[t - 1][i] & 0xff];
+}
+
 extern "C" {
+
+// The checksum TensorFlow's tensor bundle stores per tensor and per table block (tensorflow/core/lib/hash/crc32c.h;
+// what tf.train.Saver().restore verifies, test_n_est_w_experts.py:98-105): crc32c of `n` bytes continuing from `crc`
+// (0 to start).  The stored form is masked: ((crc >> 15) | (crc << 17)) + 0xa282ead8.
+uint32_t nesti_crc32c(const void* data, size_t n, uint32_t crc) {
+  static const bool once = (crc_init(), true);
+  (void)once;
+  const unsigned char* p = static_cast<const unsigned char*>(data);
+  uint32_t c = ~crc;
+  while (n && (reinterpret_cast<uintptr_t>(p) & 7)) { c = g_crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8); --n; }
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    w ^= c;
+    c = g_crc_tab[7][w & 0xff] ^ g_crc_tab[6][(w >> 8) & 0xff] ^ g_crc_tab[5][(w >> 16) & 0xff] ^ g_crc_tab[4][(w >> 24) & 0xff] ^
+        g_crc_tab[3][(w >> 32) & 0xff] ^ g_crc_tab[2][(w >> 40) & 0xff] ^ g_crc_tab[1][(w >> 48) & 0xff] ^ g_crc_tab[0][w >> 56];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = g_crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+  return ~c;
+}
 
 // np.savetxt(path, float32_array.astype(float64)) with the default fmt '%.18e' and ' ' delimiter.  Rows are
 // formatted by a few host threads into per-chunk buffers, then written in order.

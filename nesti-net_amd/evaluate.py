@@ -7,7 +7,9 @@ import numpy as np
 
 
 def shape_metrics(normals_pred, normals_gt):
-    """Both [n,3]; returns dict(rms, rms_o, pgp5, pgp10) for one shape."""
+    """Both [n,3]; returns dict(rms, rms_o, pgp5, pgp10) for one shape.  The values keep the reference's scalar types
+    (float32 for the angles' RMS -- the arrays are ``astype('float32')``, ``utils/evaluate.py:107-108`` -- float64 for
+    the portions), so that ``str()`` of them and of their means prints what the reference's log prints."""
     pred = np.asarray(normals_pred, np.float32)
     gt = np.asarray(normals_gt, np.float32)
     pred = pred / np.sqrt(np.sum(np.square(pred), axis=1))[:, None]      # :131-134
@@ -15,10 +17,10 @@ def shape_metrics(normals_pred, normals_gt):
     nn = np.sum(gt * pred, axis=1)
     nn = np.clip(nn, -1, 1)                                               # :138-139
     ang = np.rad2deg(np.arccos(np.abs(nn)))                               # unoriented :141
-    return {"rms": float(np.sqrt(np.mean(np.square(ang)))),               # :144
-            "pgp10": float(np.sum(ang < 10.0) / float(len(ang))),         # :145
-            "pgp5": float(np.sum(ang < 5.0) / float(len(ang))),           # :146
-            "rms_o": float(np.sqrt(np.mean(np.square(np.rad2deg(np.arccos(nn))))))}   # :151
+    return {"rms": np.sqrt(np.mean(np.square(ang))),                      # :144
+            "pgp10": np.float64(np.sum(ang < 10.0) / float(len(ang))),    # :145
+            "pgp5": np.float64(np.sum(ang < 5.0) / float(len(ang))),      # :146
+            "rms_o": np.sqrt(np.mean(np.square(np.rad2deg(np.arccos(nn)))))}   # :151
 
 
 def evaluate_set(normal_results_path, data_path, dataset_list_file, sparse_patches=True):
@@ -38,8 +40,14 @@ def evaluate_set(normal_results_path, data_path, dataset_list_file, sparse_patch
             if sparse_patches and not sparse_normals:
                 pred = pred[idx]
         per_shape[shape] = shape_metrics(pred, gt)
-    avg = {k: float(np.mean([m[k] for m in per_shape.values()])) for k in ("rms", "rms_o", "pgp5", "pgp10")}
+    avg = {k: np.mean([m[k] for m in per_shape.values()]) for k in ("rms", "rms_o", "pgp5", "pgp10")}   # :187-190
     return per_shape, avg
+
+
+def _list_str(values):
+    """``str(list of numpy scalars)`` as the reference's interpreter prints it (numpy 1.x scalars repr as bare numbers;
+    numpy 2 would print ``np.float32(...)`` wrappers)."""
+    return "[" + ", ".join(str(v) for v in values) + "]"
 
 
 def main(argv=None):
@@ -67,11 +75,11 @@ def main(argv=None):
             def log_string(out_str):
                 log.write(out_str + "\n")
                 print(out_str)
-            log_string("RMS per shape: " + str([per_shape[s]["rms"] for s in shapes]))
+            log_string("RMS per shape: " + _list_str([per_shape[s]["rms"] for s in shapes]))
             log_string("RMS not oriented (shape average): " + str(avg["rms"]))
             log_string("RMS oriented (shape average): " + str(avg["rms_o"]))
-            log_string("PGP10 per shape: " + str([per_shape[s]["pgp10"] for s in shapes]))
-            log_string("PGP5 per shape: " + str([per_shape[s]["pgp5"] for s in shapes]))
+            log_string("PGP10 per shape: " + _list_str([per_shape[s]["pgp10"] for s in shapes]))
+            log_string("PGP5 per shape: " + _list_str([per_shape[s]["pgp5"] for s in shapes]))
             log_string("PGP10 average: " + str(avg["pgp10"]))
             log_string("PGP5 average: " + str(avg["pgp5"]))
         results[name] = avg

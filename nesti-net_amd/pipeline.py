@@ -19,8 +19,19 @@ class NormalEstimator:
     hipGraph once and replays it; only worthwhile for small batches where launch gaps matter."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", batch=4096, seed=3627473,
-                 use_graph=False, n_streams=1, gate_margin=None):
+                 use_graph=False, n_streams=1, gate_margin=None, subsample="hash"):
         self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
+        # subsample='reference': balls larger than P are thinned exactly like the reference does (scipy cKDTree traversal
+        # order + ONE numpy RandomState stream over all patches in visiting order, utils/pcpnet_dataset.py:304-321), on the
+        # host, ~1 ms per patch -- for diffing against a real reference run row by row (refsample.py).  The default 'hash'
+        # is the GPU ball query with its order-independent uniform subset (DESIGN.md 2).
+        if subsample not in ("hash", "reference"):
+            raise ValueError("subsample must be 'hash' or 'reference'")
+        self.subsample = subsample
+        self._ref = None
+        if subsample == "reference":
+            from .refsample import ReferencePatchSampler
+            self._ref = ReferencePatchSampler(seed)
         self.use_graph = bool(use_graph)
         # n_streams > 1: consecutive batches alternate between HIP streams (own staging buffers and scratch
         # arena each), so one batch's partially filled last workgroup rounds overlap the other's kernels
@@ -85,6 +96,8 @@ class NormalEstimator:
         single_tower = self.cfg.arch in (ARCH_SINGLE, ARCH_MULTI)      # ss/ms ablations: normals only
         if first < 0 or count < 0 or first + count > cloud.patch_count:
             raise ValueError("patch rows [%d, %d) outside [0, %d)" % (first, first + count, cloud.patch_count))
+        if self._ref is not None:
+            return self._run_reference_order(cloud, first, count, normals, expert, probs, single_tower)
         if self._fused:
             qidx = cloud.pidx[first:first + count].contiguous() if cloud.pidx is not None else None
             st = torch.cuda.current_stream(self.device)
@@ -135,12 +148,31 @@ class NormalEstimator:
             return normals, None, None
         return normals, expert, probs
 
+    def _run_reference_order(self, cloud, first, count, normals, expert, probs, single_tower):
+        """Patch rows [first, first + count) with the reference's own subsample (host), then the usual forward pass."""
+        if getattr(cloud, "_ref_tree", None) is None:
+            cloud._ref_tree = self._ref.build_tree(cloud.host_pts)
+        S, P = self.cfg.n_scales, self.cfg.num_point
+        done = 0
+        while done < count:
+            take = min(self.batch, count - done)
+            rows = np.arange(first + done, first + done + take)
+            centers = cloud.pidx[first + done:first + done + take].cpu().numpy() if cloud.pidx is not None else rows
+            p, n = self._ref.patches(cloud.host_pts, cloud._ref_tree, centers, cloud.r_abs, P)
+            sl = slice(done, done + take)
+            self.net.forward(torch.from_numpy(p).to(self.device), torch.from_numpy(n).to(self.device).view(take, S),
+                             out=(normals[sl], expert[sl], probs[sl]))
+            done += take
+        if single_tower:
+            return normals, None, None
+        return normals, expert, probs
+
     def run_many(self, items):
         """Several shapes (or shards of shapes) as ONE stream of batches: ``items`` = [(cloud, first, count), ...].
         Returns one (normals, expert, probs) triple of device tensors per item (views of the concatenated outputs).
         Small shapes / shards share the gate and expert launches (``nesti_estimate_normals_multi``); results equal
         ``run`` on each item.  8^3 grid, plain mode; otherwise falls back to per-item ``run``."""
-        if not self._fused or self.cfg.n_gaussians != 8:
+        if not self._fused or self.cfg.n_gaussians != 8 or self._ref is not None:
             return [self.run(c, f, n) for c, f, n in items]
         total = sum(n for _, _, n in items)
         E = max(1, self.cfg.n_gate_out)

@@ -45,6 +45,7 @@ class CloudPatches:
             raise _lib.NestiError("CloudPatches needs a GPU: libnesti_hip.so has no CPU path")
         self.cfg, self.device, self.seed = cfg, torch.device(device), int(seed)
         pts = np.ascontiguousarray(pts, dtype=np.float32)
+        self.host_pts = pts                   # kept for the opt-in reference-order subsample (pipeline.py: subsample='reference')
         self.n_points = pts.shape[0]
         # utils/pcpnet_dataset.py:281-282 -- float64 Python arithmetic on the host, like the reference
         self.bbdiag = float(np.linalg.norm(pts.max(0) - pts.min(0), 2))

@@ -10,8 +10,11 @@
 * ``gmm.p`` -- the pickled sklearn GaussianMixture of the Gaussian grid (Python 2).
 
 No TensorFlow, sklearn or Python 2 is needed.  TensorFlow itself is not installable here and the
-reference ships no checkpoint, so this reader is pinned only against bundles written by the
-format-level writer in ``tests/test_tf_ckpt.py`` (parity unpinned against a real TF-written file).
+reference ships no checkpoint, so no TF-written file exists to read; the format primitives are pinned by independent
+known answers instead (``tests/test_tf_ckpt.py``: the RFC 3720 / LevelDB CRC-32C vectors and the masked form, varint
+edge cases, a hand-assembled prefix-compressed block, the table magic), and whole bundles against the format-level
+writer in ``tests/ckpt_writer.py``.  Like ``saver.restore``, :func:`read_bundle` verifies the stored checksums (table
+blocks and tensors) and refuses a file whose bytes do not match them.
 """
 import io
 import json
@@ -65,7 +68,7 @@ def _fields(buf):
 
 def _parse_entry(buf):
     """BundleEntryProto (tensorflow/core/protobuf/tensor_bundle.proto)."""
-    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0}
+    e = {"dtype": 0, "shape": [], "shard_id": 0, "offset": 0, "size": 0, "crc32c": 0}
     for fn, wt, v in _fields(buf):
         if fn == 1:
             e["dtype"] = v
@@ -83,15 +86,41 @@ def _parse_entry(buf):
             e["offset"] = v
         elif fn == 5:
             e["size"] = v
+        elif fn == 6 and wt == 5:                      # fixed32 crc32c (masked) of the tensor's bytes
+            e["crc32c"] = struct.unpack("<I", v)[0]
     return e
 
 
+# ---- checksums (tensorflow/core/lib/hash/crc32c.h) ---------------------------------------------
+_MASK_DELTA = 0xa282ead8
+
+
+def crc32c(data, crc=0):
+    """CRC-32C of bytes / a contiguous uint8 array (native: ``nesti_crc32c`` of libnesti_hip.so, host code)."""
+    from . import _lib
+    buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    return int(_lib.load().nesti_crc32c(_lib.ptr(buf) if buf.size else None, buf.size, crc))
+
+
+def mask_crc(crc):
+    """The stored form of a checksum: rotate right by 15 and add a constant (crc32c::Mask)."""
+    return (((crc >> 15) | (crc << 17)) + _MASK_DELTA) & 0xffffffff
+
+
+def unmask_crc(masked):
+    rot = (masked - _MASK_DELTA) & 0xffffffff
+    return ((rot >> 17) | (rot << 15)) & 0xffffffff
+
+
 # ---- LevelDB table ---------------------------------------------------------------------------
-def _read_block(data, offset, size):
+def _read_block(data, offset, size, verify=True):
     raw = data[offset:offset + size]
-    ctype = data[offset + size]                        # 1-byte compression type + 4-byte crc follow the block
+    ctype = data[offset + size]                        # 1-byte compression type + 4-byte masked crc32c(block + type) follow
     if ctype != 0:
         raise ValueError("compressed table blocks (type %d) are not supported" % ctype)
+    stored = struct.unpack("<I", data[offset + size + 1:offset + size + 5])[0]
+    if verify and stored != 0 and unmask_crc(stored) != crc32c(data[offset:offset + size + 1]):
+        raise ValueError("table block at offset %d fails its crc32c" % offset)
     n_restarts = struct.unpack("<I", raw[-4:])[0]
     end = len(raw) - 4 - 4 * n_restarts
     pos, key = 0, b""
@@ -127,8 +156,9 @@ def read_index(index_path):
     return entries
 
 
-def read_bundle(prefix):
-    """``saver.restore`` without TF: prefix e.g. ``.../model.ckpt`` -> {name: ndarray}."""
+def read_bundle(prefix, verify=True):
+    """``saver.restore`` without TF: prefix e.g. ``.../model.ckpt`` -> {name: ndarray}.  ``verify``: check every tensor's
+    stored crc32c like TF does on restore (an all-zero field means "not written" and is skipped)."""
     entries = read_index(prefix + ".index")
     shards = {}
     out = {}
@@ -140,6 +170,8 @@ def read_bundle(prefix):
             n = max(x["shard_id"] for x in entries.values()) + 1
             shards[sid] = np.memmap("%s.data-%05d-of-%05d" % (prefix, sid, n), dtype=np.uint8, mode="r")
         raw = np.asarray(shards[sid][e["offset"]:e["offset"] + e["size"]])
+        if verify and e["crc32c"] != 0 and unmask_crc(e["crc32c"]) != crc32c(raw):
+            raise ValueError("tensor %s fails its crc32c (corrupt or truncated %s)" % (name, prefix))
         out[name] = raw.view(_DTYPES[e["dtype"]]).reshape(e["shape"]).copy()
     return out
 

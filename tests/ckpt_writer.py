@@ -23,10 +23,43 @@ def _vi(n):
             return bytes(out)
 
 
-def _entry(dtype, shape, offset, size):
+_CRC_TABLE = []
+
+
+def crc32c_py(data, crc=0):
+    """Bitwise-table CRC-32C in pure Python: independent of the library's nesti_crc32c (which the reader uses)."""
+    if not _CRC_TABLE:
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            _CRC_TABLE.append(c)
+    c = crc ^ 0xffffffff
+    for b in bytes(data):
+        c = _CRC_TABLE[(c ^ b) & 0xff] ^ (c >> 8)
+    return c ^ 0xffffffff
+
+
+def masked(crc):
+    return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xffffffff
+
+
+def _crc_fn(kind):
+    """'python': the independent implementation above (small bundles); 'native': the library's (the 100 MB model of the
+    GPU end-to-end test); None: write zeros = "no checksum"."""
+    if kind == "python":
+        return crc32c_py
+    if kind == "native":
+        import nesti_net_amd  # noqa: F401
+        from nesti_net_amd import tf_ckpt
+        return tf_ckpt.crc32c
+    return None
+
+
+def _entry(dtype, shape, offset, size, crc=0):
     dims = b"".join(b"\x12" + _vi(len(_vi(d)) + 1) + b"\x08" + _vi(d) for d in shape)      # dim { size }
     msg = b"\x08" + _vi(dtype) + b"\x12" + _vi(len(dims)) + dims
-    msg += b"\x18" + _vi(0) + b"\x20" + _vi(offset) + b"\x28" + _vi(size) + b"\x35" + struct.pack("<I", 0)
+    msg += b"\x18" + _vi(0) + b"\x20" + _vi(offset) + b"\x28" + _vi(size) + b"\x35" + struct.pack("<I", crc)
     return msg
 
 
@@ -47,25 +80,28 @@ def _block(items, restart_interval=16):
     return bytes(buf)
 
 
-def write_bundle(prefix, tensors, per_block=7):
-    """Minimal tensor-bundle writer: uncompressed table, several data blocks, one shard."""
+def write_bundle(prefix, tensors, per_block=7, crc="python"):
+    """Minimal tensor-bundle writer: uncompressed table, several data blocks, one shard; masked crc32c per tensor and
+    per table block like TF writes them (``crc``: see _crc_fn)."""
+    fn = _crc_fn(crc)
+    trailer = (lambda blk: b"\x00" + struct.pack("<I", masked(fn(blk + b"\x00")))) if fn else (lambda blk: b"\x00" + struct.pack("<I", 0))
     data, items = bytearray(), [(b"", b"\x08\x01")]                       # header entry (empty key)
     for name in sorted(tensors):
         a = np.ascontiguousarray(tensors[name], dtype=np.float32)
-        items.append((name.encode(), _entry(1, a.shape, len(data), a.nbytes)))
+        items.append((name.encode(), _entry(1, a.shape, len(data), a.nbytes, masked(fn(a.tobytes())) if fn else 0)))
         data += a.tobytes()
     open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
     out, index_items = bytearray(), []
     for i in range(0, len(items), per_block):
         blk = _block(items[i:i + per_block], restart_interval=3)
         index_items.append((items[min(i + per_block, len(items)) - 1][0], _vi(len(out)) + _vi(len(blk))))
-        out += blk + b"\x00" + struct.pack("<I", 0)                         # type + crc trailer
+        out += blk + trailer(blk)                                           # type + crc trailer
     meta = _block([])
     meta_h = _vi(len(out)) + _vi(len(meta))
-    out += meta + b"\x00" + struct.pack("<I", 0)
+    out += meta + trailer(meta)
     idx = _block(index_items, restart_interval=1)
     idx_h = _vi(len(out)) + _vi(len(idx))
-    out += idx + b"\x00" + struct.pack("<I", 0)
+    out += idx + trailer(idx)
     footer = (meta_h + idx_h).ljust(40, b"\x00") + struct.pack("<Q", 0xdb4775248b80fb57)
     open(prefix + ".index", "wb").write(bytes(out) + footer)
 
@@ -89,7 +125,7 @@ def tf_names(W, uniquified=False):
     return out
 
 
-def write_model_dir(path, cfg, W, uniquified=False, per_block=50):
+def write_model_dir(path, cfg, W, uniquified=False, per_block=50, crc="native"):
     """parameters.p + gmm.p + model.ckpt.* as train_n_est_w_experts.py:120-122, 248-250, 353-354 leave them."""
     import os
     ns = argparse.Namespace(patch_radius=list(cfg.patch_radius), num_point=cfg.num_point, n_experts=cfg.n_experts,
@@ -110,6 +146,6 @@ def write_model_dir(path, cfg, W, uniquified=False, per_block=50):
         pickle.dump(g, open(os.path.join(path, "gmm.p"), "wb"), protocol=2)
     finally:
         del sys.modules["sklearn.mixture.gaussian_mixture"]
-    write_bundle(os.path.join(path, "model.ckpt"), tf_names(W, uniquified), per_block=per_block)
+    write_bundle(os.path.join(path, "model.ckpt"), tf_names(W, uniquified), per_block=per_block, crc=crc)
 
 

@@ -1,4 +1,9 @@
+import os
+import re
+
 import numpy as np
+
+from conftest import GOLDEN
 
 
 def test_shape_metrics_definitions():
@@ -38,3 +43,31 @@ def test_evaluate_cli_writes_reference_summary(tmp_path):
     lines = (res / "summary" / "myset_evaluation_results.txt").read_text().splitlines()
     assert len(lines) == 7 and lines[0].startswith("RMS per shape: [") and lines[1].startswith("RMS not oriented (shape average): ")
     assert lines[6].startswith("PGP5 average: ")
+
+
+def test_evaluate_matches_the_reference_script_output(tmp_path):
+    """tests/golden/eval_ref.npz holds a synthetic dataset and the summary files the reference's OWN utils/evaluate.py
+    wrote for it (scripts/make_golden_eval.py, run in the build container): our command-line twin must write the same
+    seven lines per dataset list, byte for byte once numpy 2's ``np.float32(..)`` scalar wrappers are removed from the
+    reference's list lines (the reference's interpreter prints bare numbers there)."""
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd.evaluate import main
+    g = np.load(os.path.join(GOLDEN, "eval_ref.npz"))
+    data, res = str(tmp_path / "data") + "/", str(tmp_path / "res") + "/"
+    os.makedirs(data)
+    os.makedirs(res)
+    for name in g["shape_names"]:
+        np.savetxt(data + name + ".xyz", g[name + "_xyz"])
+        np.savetxt(data + name + ".normals", g[name + "_gt"])
+        np.savetxt(data + name + ".pidx", g[name + "_pidx"], fmt="%d")
+        np.savetxt(res + name + ".normals", g[name + "_pred"])
+    lists = [str(x) for x in g["list_names"]]
+    for ln in lists:
+        with open(data + ln + ".txt", "w") as f:
+            f.write("\n".join(str(x) for x in g["list_" + ln]) + "\n\n")
+    main(["--normal_results_path", res, "--data_path", data, "--dataset_list"] + lists)
+    for ln in lists:
+        want = re.sub(r"np\.float(?:32|64)\(([^)]*)\)", r"\1", str(g["summary_" + ln]))
+        got = open(os.path.join(res, "summary", ln + "_evaluation_results.txt")).read()
+        assert got == want, (got, want)
+        assert len(want.splitlines()) == 7

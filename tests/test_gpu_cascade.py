@@ -5,7 +5,7 @@ the gate margin tau are decided by the f16x3 gating net; the experts always run 
 What must hold, whatever tau is: the normals of a query are the f16x3 normals of the expert it was routed to; with
 tau = inf every output equals the f16x3 mode bit for bit; with tau = 0 the arg-max is the plain f16 gate's; with the
 calibrated tau the arg-max equals the f16x3 arg-max on every query and the f16 gate's measured error on a logit difference
-(nesti_model_cascade_stats) stays below tau / 2."""
+(nesti_model_cascade_stats) stays below 0.8 tau."""
 import numpy as np
 import pytest
 import torch
@@ -83,7 +83,7 @@ def test_calibrated_margin_reproduces_the_f16x3_decisions(case, gpu_device):
     st = net.cascade_stats()
     print("tau", tau, st, "f16 gate flips", int((e16 != ref[1]).sum().item()))
     assert st["queries"] == B and 0 < st["rechecked"] < B // 2          # a filter, not a second full pass
-    assert st["max_margin_err"] <= tau / 2                              # the bound tau rests on, re-measured on this batch
+    assert st["max_margin_err"] < 0.8 * tau and tau >= 6.9 * st["sigma"]   # what tau rests on, re-measured on this batch
     assert torch.equal(expert, ref[1]) and torch.equal(normals, ref[0])
     # probabilities: f16x3's on the rechecked rows, the f16 gate's elsewhere
     same = (probs == ref[2]).all(dim=1)

@@ -353,3 +353,29 @@ def test_run_many_equals_per_shape_runs(gpu_device):
         ref = est.run(c, f, n)
         for x, y in zip(got, ref):
             assert torch.equal(x, y)
+
+
+def test_reference_order_subsample_feeds_the_same_forward(gpu_device):
+    """NormalEstimator(subsample='reference'): the reference's own thinning of balls larger than P (host: scipy cKDTree +
+    one RandomState stream in visiting order, utils/pcpnet_dataset.py:304-321) in front of the usual forward pass.  On the
+    100k golden fixture -- 32 queries, the largest scale capped on every one -- the outputs equal a forward pass over
+    the patch tensors the reference dataset itself produced, bit for bit, and a second cloud continues the stream."""
+    from conftest import golden_patch_files, load_golden_patches
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from nesti_net_amd.pipeline import NormalEstimator
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid100k" in p][0])
+    cfg = NestiConfig()
+    W = weights.synthetic_weights(cfg)
+    net = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=len(g["queries"]))
+    want = [t.cpu().numpy() for t in net(torch.as_tensor(g["points"], device=gpu_device), torch.as_tensor(g["n_eff"], device=gpu_device))]
+    est = NormalEstimator(cfg, W, dtype="f16x3", device=gpu_device, batch=10, seed=g["seed"], subsample="reference")
+    got = est.estimate(g["pts"], pidx=g["queries"])
+    assert (g["n_eff"] == cfg.num_point).any()
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    again = est.estimate(g["pts"], pidx=g["queries"])           # the stream has moved on: capped rows are thinned differently
+    assert not np.array_equal(again[0], got[0])
+    with pytest.raises(ValueError):
+        NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=4, subsample="sorted")
