@@ -39,8 +39,8 @@ from nesti_net_amd.config import NestiConfig  # noqa: E402
 from nesti_net_amd.pipeline import NormalEstimator  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x3": 2500.0, "f16x3c": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
-# library batch caps by workspace (MB per query: f16 gate 2.0, f16x3 gate 5.9, f16x3 expert 3.8 -- nesti_tower_workspace_bytes)
-MAX_BATCH = {"bf16x3": 33400, "f16x3": 33400, "f16x3c": 50000, "f32": 8192}
+# library batch caps by workspace (MB per query: f16 gate 2.0, f16x3 gate 3.9, f16x3 expert 2.6 -- nesti_tower_workspace_bytes)
+MAX_BATCH = {"bf16x3": 50000, "f16x3": 50000, "f32": 8192}
 PRODUCTS = {"bf16": 1, "f16": 1, "f32": 1, "bf16x3": 3, "f16x3": 3}   # MFMA products per multiply
 
 

@@ -98,8 +98,8 @@ int nesti_gmm_grid(int n, double variance, float* w, float* mu, float* sigma);
  *              scale s, statistic c; channels >= 20*S are written as zero.
  * Rows whose n_eff is 0 (the zero-padded tail of the reference's last batch,
  * test_n_est_w_experts.py:134-140) are written as zeros instead of NaN.
- * out_dtype NESTI_BF16X3 / NESTI_F16X3: out_cstride is a multiple of 192 16-bit elements and channel c is stored as the planes
- * hi at 192*(c/64) + c%64, lo 64 elements further, hi again 128 elements further (value = hi + lo). */
+ * out_dtype NESTI_BF16X3 / NESTI_F16X3: out_cstride is a multiple of 128 16-bit elements and channel c is stored as the planes
+ * hi at 128*(c/64) + c%64 and lo 64 elements further (value = hi + lo). */
 int nesti_mups_forward(const nesti_config_t* cfg, const float* points_dev,
                        const int32_t* n_eff_dev, int B, void* out_dev, int out_dtype,
                        int out_cstride, void* stream);
@@ -180,7 +180,7 @@ size_t nesti_tower_workspace_bytes(const nesti_config_t* cfg, int dtype, int tow
 /* Scratch size for forward calls of up to max_batch points. */
 size_t nesti_workspace_bytes(const nesti_model_t* m, int max_batch);
 int nesti_model_mups_cstride(const nesti_model_t* m); /* channel stride of the internal MuPS tensor, in elements
-                                                       * (NESTI_BF16X3 / NESTI_F16X3: 3 x the padded channel count) */
+                                                       * (NESTI_BF16X3 / NESTI_F16X3: 2 x the padded channel count) */
 int nesti_model_mups_rows(const nesti_model_t* m);    /* rows per point of the internal MuPS tensor: 512 (8^3 grid)
                                                        * or 64 (3^3 grid: row 16i+4j+k of a 4^3 index space, rows with
                                                        * a coordinate of 3 are zero) */

@@ -27,16 +27,17 @@ void set_error(const std::string& msg);
   } while (0)
 
 static inline size_t dtype_size(int dt) { return dt == NESTI_F32 ? 4 : 2; }
-// NESTI_BF16X3: the kernels are the bf16 ones; an activation row holds, per group of 64 channels, the three 64-element
-// planes [hi | lo | hi] (192 elements), and the packed weights the matching K order [W_hi ; W_hi ; W_lo], so that the
-// unchanged K loop accumulates hi*W_hi + lo*W_hi + hi*W_lo.  Writers emit the planes (split_col / split_pack2 below).
+// NESTI_BF16X3: the kernels are the bf16 ones with the pair K loop (conv.hip / conv8.hip: X3); an activation row holds, per
+// group of 64 channels, the two 64-element planes [hi | lo] (128 elements), a packed weight row [W_hi | W_lo] per K chunk,
+// and one set of fragment reads feeds hi*W_hi + lo*W_hi + hi*W_lo.  Writers emit the planes (split_col / split_pack2 below).
 // NESTI_F16X3: the same with f16 pairs and the f16 kernels.
 // NESTI_F16X3C is NESTI_F16X3 everywhere except in the gating net's first pass (model.hip: gate_cascade)
 static inline int main_dtype(int dt) { return dt == NESTI_F16X3C ? NESTI_F16X3 : dt; }
 static inline int kernel_dtype(int dt) { return dt == NESTI_BF16X3 ? NESTI_BF16 : dt == NESTI_F16X3 ? NESTI_F16 : dt; }
-static inline int act_planes(int dt) { return (dt == NESTI_BF16X3 || dt == NESTI_F16X3) ? 3 : 1; }
+constexpr int kPairPlanes = 2;    // hi, lo
+static inline int act_planes(int dt) { return (dt == NESTI_BF16X3 || dt == NESTI_F16X3) ? kPairPlanes : 1; }
 constexpr int kSplitGroup = 64;
-__host__ __device__ __forceinline__ int split_col(int col) { return (col >> 6) * (3 * kSplitGroup) + (col & (kSplitGroup - 1)); }
+__host__ __device__ __forceinline__ int split_col(int col) { return (col >> 6) * (kPairPlanes * kSplitGroup) + (col & (kSplitGroup - 1)); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- element conversion (device) ------------------------------------------
@@ -103,7 +104,6 @@ __device__ __forceinline__ void store_act4(unsigned char* base, long long row_el
   unsigned char* d0 = base + (row_elems + split_col(col)) * 2;
   *reinterpret_cast<uint2*>(d0) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(d0 + 2 * kSplitGroup) = make_uint2(l0, l1);
-  *reinterpret_cast<uint2*>(d0 + 4 * kSplitGroup) = make_uint2(h0, h1);
 }
 template <class E>
 __device__ __forceinline__ void store_act8(unsigned char* base, long long row_elems, int col, const float4& f0, const float4& f1, int split) {
@@ -120,10 +120,9 @@ __device__ __forceinline__ void store_act8(unsigned char* base, long long row_el
   unsigned char* d0 = base + (row_elems + split_col(col)) * 2;
   *reinterpret_cast<uint4*>(d0) = h;
   *reinterpret_cast<uint4*>(d0 + 2 * kSplitGroup) = l;
-  *reinterpret_cast<uint4*>(d0 + 4 * kSplitGroup) = h;
 }
 
-// the pair modes as store types (mups.hip): 16-bit elements, three planes
+// the pair modes as store types (mups.hip): 16-bit elements, two planes
 template <> struct Elem<NESTI_BF16X3> : Elem<NESTI_BF16> {};
 template <> struct Elem<NESTI_F16X3> : Elem<NESTI_F16> {};
 template <int DT> constexpr bool is_x3 = (DT == NESTI_BF16X3 || DT == NESTI_F16X3);

@@ -72,7 +72,11 @@ struct SwzKey {
   __device__ __forceinline__ int operator()(int row) const { return ((row >> 1) & m_lo) | (((row >> 6) & m_hi) << 1); }
 };
 
-template <int DT, int TN, bool KPIPE>
+// X3 (the pair modes NESTI_F16X3 / NESTI_BF16X3): an activation row holds, per 64-channel group, the planes [hi 64 | lo 64]; a K
+// chunk is 32 channels -- the LDS row [hi k0..31 | lo k0..31], staged from the two planes, the weight row [W_hi | W_lo] --
+// and one set of fragment reads feeds three MFMAs (lo * W_hi, hi * W_hi, hi * W_lo): 1.5x the MFMAs per LDS byte, per
+// staged byte and per barrier of the plain kernel.
+template <int DT, int TN, bool KPIPE, bool X3>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NI = TN / 32;
@@ -116,7 +120,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
       long long pt = gr >> log2V;
       const long long vox = gr & (V - 1);
       if (p.point_index) pt = p.point_index[pt];
-      a_off[j] = (((pt << log2V) + vox) * p.in_cstride + p.in_coff) * kEsz + slot * 16;
+      a_off[j] = (((pt << log2V) + vox) * p.in_cstride + p.in_coff) * kEsz +
+                 (X3 ? (slot & 3) * 16 + (slot >> 2) * (2 * kSplitGroup) : slot * 16);
     } else {
       a_off[j] = -1;
     }
@@ -130,7 +135,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (a_off[j] >= 0)
-        glds16(in_b + a_off[j] + (long long)c * kRowBytes, lds0 + a_buf * kABytes + (wave * 8 + j) * 1024);
+        glds16(in_b + a_off[j] + (X3 ? (long long)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (c & 1) * 64 : (long long)c * kRowBytes),
+               lds0 + a_buf * kABytes + (wave * 8 + j) * 1024);
   };
   auto stage_b = [&](int c, int t, int b_buf) __attribute__((always_inline)) {
     const unsigned char* src = w_tile + ((size_t)c * p.n_taps + t) * kBTile;
@@ -169,6 +175,53 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   // branched over (its fragment reads hit the zero row).
   auto compute = [&](const bool live0, const bool live1, const unsigned char* Acur, const unsigned char* Bcur,
                      const int (&a_addr)[2], const int (&a_sw)[2]) __attribute__((always_inline)) {
+    if constexpr (X3) {
+      // fragment sets of one 16-channel K-step t: hi / lo of the two M tiles, W_hi / W_lo of the NI N tiles.  The three
+      // products run lo*W_hi, hi*W_hi, hi*W_lo, and each set is reloaded for step t + 1 as soon as its last product has
+      // been issued, so every read has at least 2 x NI MFMAs to land (no extra registers: 4 + 2 NI fragments).
+      uint4 ah[2], al[2], bh[NI], bl[NI];
+      auto ld_a = [&](int t, int lo, uint4 (&f)[2]) __attribute__((always_inline)) {
+        const int slot = lo * 4 + t * 2 + khalf;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) f[mi] = *reinterpret_cast<const uint4*>(Acur + a_addr[mi] + ((slot ^ a_sw[mi]) << 4));
+      };
+      auto ld_b = [&](int t, int lo, uint4 (&f)[NI]) __attribute__((always_inline)) {
+        const int slot = lo * 4 + t * 2 + khalf;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          f[ni] = *reinterpret_cast<const uint4*>(Bcur + ni * 32 * kRowBytes + b_row + ((slot ^ b_sw) << 4));
+      };
+      auto mm = [&](const uint4 (&af)[2], const uint4 (&bf)[NI]) __attribute__((always_inline)) {
+        if (KPIPE || live0) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[0][ni], af[0], bf[ni]);
+        }
+        if (KPIPE || live1) {
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[1][ni], af[1], bf[ni]);
+        }
+      };
+      ld_a(0, 1, al);
+      ld_b(0, 0, bh);
+      ld_a(0, 0, ah);
+      ld_b(0, 1, bl);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+        mm(al, bh);
+        if (t < 1) ld_a(t + 1, 1, al);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah, bh);
+        if (t < 1) ld_b(t + 1, 0, bh);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(ah, bl);
+        if (t < 1) {
+          ld_a(t + 1, 0, ah);
+          ld_b(t + 1, 1, bl);
+        }
+      }
+      return;
+    }
     uint4 a[2][2], b[2][NI];
     auto load_frags = [&](int kk, uint4 (&af)[2], uint4 (&bf)[NI]) __attribute__((always_inline)) {
       const int slot = kk * 2 + khalf;
@@ -549,7 +602,7 @@ constexpr size_t lds_bytes() {
   return loop > kPoolTile ? loop : kPoolTile;
 }
 
-template <int DT, int TN, bool KPIPE>
+template <int DT, int TN, bool KPIPE, bool X3>
 int launch_one(const ConvParams& p, hipStream_t stream) {
   // the dynamic-LDS opt-in is a per-device function attribute: one flag per device, not per process
   constexpr int kMaxDevices = 64;
@@ -560,13 +613,13 @@ int launch_one(const ConvParams& p, hipStream_t stream) {
   static_assert(lds <= 163840, "LDS budget");
   static_assert(!KPIPE || lds >= (size_t)kTileM * kPoolStride + 16, "pooling tile + zero slot must fit");
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
-    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN, KPIPE>),
+    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN, KPIPE, X3>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
   }
   const int groups = (p.m_tiles + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * p.n_tiles)), block(kThreads);
-  hipLaunchKernelGGL((conv_igemm_kernel<DT, TN, KPIPE>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<DT, TN, KPIPE, X3>), grid, block, lds, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -574,8 +627,16 @@ int launch_one(const ConvParams& p, hipStream_t stream) {
 template <int DT>
 int launch_dt(const ConvParams& p, int TN, hipStream_t stream) {
   const bool kpipe = (p.n_taps == 1);
-  if (TN == 128) return kpipe ? launch_one<DT, 128, true>(p, stream) : launch_one<DT, 128, false>(p, stream);
-  if (TN == 64) return kpipe ? launch_one<DT, 64, true>(p, stream) : launch_one<DT, 64, false>(p, stream);
+  if constexpr (DT != NESTI_F32) {
+    if (p.x3native) {
+      if (TN == 128) return kpipe ? launch_one<DT, 128, true, true>(p, stream) : launch_one<DT, 128, false, true>(p, stream);
+      if (TN == 64) return kpipe ? launch_one<DT, 64, true, true>(p, stream) : launch_one<DT, 64, false, true>(p, stream);
+      NESTI_FAIL("launch_conv: unsupported N tile");
+    }
+  }
+  if (p.x3native) NESTI_FAIL("launch_conv: the pair K loop is for the 16-bit kernels");
+  if (TN == 128) return kpipe ? launch_one<DT, 128, true, false>(p, stream) : launch_one<DT, 128, false, false>(p, stream);
+  if (TN == 64) return kpipe ? launch_one<DT, 64, true, false>(p, stream) : launch_one<DT, 64, false, false>(p, stream);
   NESTI_FAIL("launch_conv: unsupported N tile");
 }
 

@@ -63,10 +63,10 @@ __device__ __forceinline__ uint4 lds128(unsigned addr) {
 }
 
 // X3 (pair modes, model.hip: PackedLayer::x3n): the K chunk is 16 channels -- an LDS row holds [hi k0..15 | lo k0..15] of the
-// activation pair (staged from planes 0 and 1 of the [hi | lo | hi] row groups) and a weight row [W_hi k0..15 | W_lo k0..15]
+// activation pair (staged from the two planes of the [hi 64 | lo 64] row groups) and a weight row [W_hi k0..15 | W_lo k0..15]
 // -- and a tap multiplies hi * W_hi + lo * W_hi + hi * W_lo from ONE set of fragment reads: three MFMAs per 2 + 2/8
-// ds_read_b128 instead of two, and a third fewer (chunk, tap) steps, barriers and staged bytes than running the pair as
-// three planes through the plain kernel.
+// ds_read_b128 instead of two (round 3, same box: -7 % on these layers against running the pair as three planes [hi | lo | hi]
+// with weights [W_hi ; W_hi ; W_lo] through the plain kernel; the time of these kernels follows LDS bytes per MFMA).
 template <int DT, int K, bool X3>
 __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
     for (int j = 0; j < 8; ++j) {
       if (!(tiles & (1u << j))) continue;
       const int y = (wave - j) & 7;                      // tile (y, z = j) of this wave
-      // X3: chunk c = channels [16 c, 16 c + 16) of 64-channel group c >> 2, whose planes sit 128 B apart in a 384-B run
+      // X3: chunk c = channels [16 c, 16 c + 16) of 64-channel group c >> 2, whose two planes sit 128 B apart in a 256-B run
       const unsigned char* src = in_b + (size_t)((j * 64 + y * 8) * p.in_cstride) * kEsz +
-                                 (X3 ? (size_t)(c >> 2) * (6 * kSplitGroup) + (size_t)(c & 3) * 32 : (size_t)c * 64);
+                                 (X3 ? (size_t)(c >> 2) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 3) * 32 : (size_t)c * 64);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         if (a_ok[h]) glds16(src + a_voff[h], lds0 + kAOff + (wave * 8 + j) * kTileBytes + h * 1024);

@@ -47,11 +47,11 @@ struct ConvParams {
   // 8 points (4^3), dealt to the 4 SIMDs as a Latin square so that the tiles a padding tap skips are spread evenly
   // over the matrix pipes (conv.hip: tile_row).  0 = tile t holds rows [32t, 32t+32).
   int remap;
-  // NESTI_BF16X3 / NESTI_F16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (three planes per
-  // 64-channel group); out_coff / out_coff2 stay logical and every 16-bit store goes through split_col + three planes.
+  // NESTI_BF16X3 / NESTI_F16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (two planes per
+  // 64-channel group); out_coff / out_coff2 stay logical and every 16-bit store goes through split_col + two planes.
   int split;
-  int x3native;        // pair modes, conv8_kernel: K chunks of 16 channels [hi | lo] with three MFMAs per fragment set (conv8.hip: X3)
-                       // instead of the three planes as 3 x the channels; the packed weights follow (model.hip: PackedLayer::x3n)
+  int x3native;        // pair modes: the kernels' pair K loop (conv.hip / conv8.hip: X3) -- K chunks [hi | lo] x [W_hi | W_lo], three MFMAs
+                       // per fragment set; the packed weights follow (model.hip: PackedLayer::x3n)
   float acc_scale;     // the accumulators are multiplied by this before the bias (1, or 2^-s when the layer's packed weights
                        // carry a 2^s scale: NESTI_F16X3 keeps the weight pairs in f16's normal range that way)
   int8_t tap[kMaxTaps][4];   // dz, dy, dx, -
@@ -89,6 +89,8 @@ int launch_gate_flag(const float* logits, int lstride, int B, int E, float tau, 
                      unsigned long long* cstat, hipStream_t stream);
 int launch_gate_recheck(const float* logits, int lstride, const int32_t* flag_list, const int32_t* count_ptr, int cap, int E,
                         const float* keep, float* probs, int32_t* expert, unsigned long long* cstat, hipStream_t stream);
+// out[i * n_rounds + r] = clamp(counts[i] - r * cap, 0, cap): the rows of list i that round r of a `cap`-row tower covers
+int launch_round_counts(const int32_t* counts, int n_lists, int cap, int n_rounds, int32_t* out, hipStream_t stream);
 // ms_sw_n_est's switch (models/ms_sw_n_est.py:80-82): noise = logits[b*lstride]; expert = noise < threshold ? 0 : 1;
 // probs[b] = noise (one column); optional routing lists over the 2 towers.
 int launch_switch_finish(const float* logits, int lstride, int B, float threshold, float* probs,

@@ -529,34 +529,29 @@ bool use_conv8(const LayerDesc& d) {
   return (d.k == 5 && mode >= 1) || (d.k == 3 && mode >= 2);
 }
 
-// Error attribution in the pair modes (scripts/exp_attribution.py): NESTI_X3_PLAIN = "regex[:bits],regex[:bits],..." -- a layer
-// whose scope matches drops the products named by bits (1: lo * W_hi, 2: hi * W_lo; default 3 = both, i.e. the layer
-// computes what the plain 16-bit mode computes) by packing zeros into those weight planes.  Read at every model creation.
+// Error attribution in the pair modes (scripts/exp_attribution.py): NESTI_X3_PLAIN = "regex,regex,..." -- a layer whose scope
+// matches drops the hi * W_lo product (its W_lo weights are packed as zeros: the layer then sees its weights rounded to 16 bits).
+// Round 3's full sweep (profiles/r03_attribution_sweep.txt) also switched off lo * W_hi per layer; that needed the three-plane
+// layout [hi | lo | hi] x [W_hi ; W_hi ; W_lo] of commit 6f246d7 and is not available in the two-plane layout.
+// Read at every model creation.
 int x3_drop_mask(const LayerDesc& d) {
   const char* e = getenv("NESTI_X3_PLAIN");
   if (!e || !*e) return 0;
   std::string spec(e);
-  int mask = 0;
   size_t pos = 0;
   while (pos <= spec.size()) {
     size_t end = spec.find(',', pos);
     if (end == std::string::npos) end = spec.size();
-    std::string item = spec.substr(pos, end - pos);
+    const std::string item = spec.substr(pos, end - pos);
     pos = end + 1;
     if (item.empty()) continue;
-    int bits = 3;
-    const size_t colon = item.rfind(':');
-    if (colon != std::string::npos && colon + 1 < item.size() && isdigit((unsigned char)item[colon + 1])) {
-      bits = atoi(item.c_str() + colon + 1) & 3;
-      item = item.substr(0, colon);
-    }
     try {
       const std::regex re(item);
-      if (std::regex_search(d.scope, re) || (!d.scope2.empty() && std::regex_search(d.scope2, re))) mask |= bits;
+      if (std::regex_search(d.scope, re) || (!d.scope2.empty() && std::regex_search(d.scope2, re))) return 2;
     } catch (const std::regex_error&) {
     }
   }
-  return mask;
+  return 0;
 }
 
 int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer* pl) {
@@ -580,18 +575,16 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
         ++pl->n_taps;
       }
   const size_t esz = dtype_size(dtype);
-  // NESTI_BF16X3 / NESTI_F16X3 (common.h): K runs over the physical input row -- per 64-channel group the planes [hi | lo | hi] -- and
-  // the weights follow it as [W_hi ; W_hi ; W_lo], so the unchanged K loop accumulates hi*W_hi + lo*W_hi + hi*W_lo
+  // NESTI_BF16X3 / NESTI_F16X3 (common.h): a K chunk of a packed weight row is [W_hi | W_lo] for half as many channels as the
+  // plain chunk holds (the kernels' pair K loop multiplies hi*W_hi + lo*W_hi + hi*W_lo from it: conv.hip / conv8.hip, X3)
   const int planes = act_planes(dtype);
-  const int drop = planes == 3 ? x3_drop_mask(d) : 0;
+  const int drop = planes > 1 ? x3_drop_mask(d) : 0;
   pl->kind = use_conv8(d) ? 1 : 0;
-  // NESTI_X3_NATIVE=0: the pair modes run conv8_kernel on the three planes like every other kernel (same-box A/B, and the
-  // attribution sweep, whose per-product switches need the plane layout)
-  static const bool x3_native = [] { const char* e = getenv("NESTI_X3_NATIVE"); return e ? atoi(e) != 0 : true; }();
-  pl->x3n = pl->kind == 1 && planes == 3 && x3_native && drop == 0;
-  const int K_phys = pl->x3n ? d.Cin_p * 2 : d.Cin_p * planes;   // x3n: [hi 16 | lo 16] per chunk
+  pl->x3n = planes > 1;
+  const int K_phys = d.Cin_p * planes;
   const int row_bytes = pl->kind == 1 ? 64 : kRowBytes;   // bytes of one K chunk of one row
   const int KC = row_bytes / (int)esz;
+  const int chunk_ch = KC / planes;                       // input channels per K chunk
   pl->TN = pl->kind == 1 ? 32 : (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
   pl->n_tiles = d.Cout_p / pl->TN;
   pl->split_tile = part_p / pl->TN * (n_parts == 2 ? 1 : n_parts);
@@ -636,12 +629,11 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
         unsigned char* tile = host.data() + (((size_t)nt * pl->n_chunks + ch) * pl->n_taps + t) * tile_bytes;
         const float* wt = f.w + (size_t)tap_widx[t] * d.cin * d.cout;
         for (int kc = 0; kc < KC; ++kc) {
-          const int q = ch * KC + kc;                        // physical K position
-          // weight plane of this K position (0 / 1: W_hi, 2: W_lo) and the padded input channel it multiplies
-          const int plane = pl->x3n ? (kc < 16 ? 0 : 2) : planes == 1 ? 0 : (q % (3 * kSplitGroup)) / kSplitGroup;
-          const int cr = inv[pl->x3n ? ch * 16 + (kc & 15) : planes == 1 ? q : (q / (3 * kSplitGroup)) * kSplitGroup + q % kSplitGroup];
+          // which half of the row this K position is (0: W_hi, 1: W_lo) and the padded input channel it multiplies
+          const int plane = kc / chunk_ch;
+          const int cr = inv[ch * chunk_ch + kc % chunk_ch];
           if (cr < 0) continue;
-          if ((plane == 1 && (drop & 1)) || (plane == 2 && (drop & 2))) continue;
+          if (plane == 1 && (drop & 2)) continue;
           const float* wrow = wt + (size_t)cr * d.cout;
           const int slot = kc / per_slot, within = kc % per_slot;
           for (int nl = 0; nl < pl->TN; ++nl) {
@@ -653,10 +645,10 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
                 ? tile + (size_t)nl * 64 + ((slot ^ ((nl >> 2) & 3)) << 4) + within * esz
                 : tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
             if (dtype == NESTI_F32) memcpy(dst, &v, 4);
-            else if (planes == 3) {
+            else if (planes > 1) {
               const bool b16 = dtype == NESTI_BF16X3;
               uint16_t h = b16 ? host_f32_to_bf16(v) : host_f32_to_f16(v);
-              if (plane == 2) {                              // W_lo = rne(W - W_hi)
+              if (plane == 1) {                              // W_lo = rne(W - W_hi)
                 float hf;
                 if (b16) { const uint32_t hb = (uint32_t)h << 16; memcpy(&hf, &hb, 4); } else hf = host_f16_to_f32(h);
                 h = b16 ? host_f32_to_bf16(v - hf) : host_f32_to_f16(v - hf);
@@ -839,7 +831,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
   return 0;
 }
 
-// channel stride of the MuPS rows the towers read, in elements (pair modes: three planes per 64-channel group)
+// channel stride of the MuPS rows the towers read, in elements (pair modes: two planes per 64-channel group)
 int mups_stride(const nesti_model* m) { return m->graph.mups_cstride * act_planes(m->dtype); }
 
 // NESTI_F16X3C: the f16x3 gate re-decides the flagged rows `cap` at a time (its workspace is 3x the filter's per row, and
@@ -847,15 +839,20 @@ int mups_stride(const nesti_model* m) { return m->graph.mups_cstride * act_plane
 int cascade_cap(int NB) { return NB <= 4096 ? NB : (int)align_up((size_t)(NB + 3) / 4, 256); }
 int cascade_rounds(int NB) { return (NB + cascade_cap(NB) - 1) / cascade_cap(NB); }
 
+// A routed expert sees about 1 / E of a batch, so its tower is sized for a quarter of a large batch and run in up to four
+// rounds over its routing list (rounds beyond the list's length launch empty grids: ~0.2 % of a 100k batch); the workspace of a
+// batch is then set by the gating net alone and a whole 100k-point cloud is one library batch in every mode but f16x3 / f32.
+int expert_cap(int NB) { return NB <= 8192 ? NB : (int)align_up((size_t)(NB + 3) / 4, 256); }
+
 size_t max_tower_bytes(const nesti_model* m, int NB) {
   size_t t = m->cascade ? std::max(tower_bytes(m->graph.gate, NB, NESTI_F16), tower_bytes(m->graph.gate, cascade_cap(NB), m->dtype))
                         : tower_bytes(m->graph.gate, NB, m->dtype);
-  for (const Tower& e : m->graph.experts) t = std::max(t, tower_bytes(e, NB, m->dtype));
+  for (const Tower& e : m->graph.experts) t = std::max(t, tower_bytes(e, expert_cap(NB), m->dtype));
   return t;
 }
 
 struct WsLayout {
-  size_t x0, probs, expert, counts, lists, keep, flags, fcounts, tower, total;
+  size_t x0, probs, expert, counts, lists, ecounts, keep, flags, fcounts, tower, total;
 };
 WsLayout ws_layout(const nesti_model* m, int NB) {
   WsLayout L;
@@ -866,6 +863,7 @@ WsLayout ws_layout(const nesti_model* m, int NB) {
   L.expert = o; o += align_up((size_t)NB * 4, 256);
   L.counts = o; o += 256;
   L.lists = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
+  L.ecounts = o; o += 1024;          // [E][rounds] rows of each expert round
   L.keep = L.flags = L.fcounts = o;
   if (m->cascade) {   // the f16 gate's logits, the flag list, [flag count | per-round counts]
     L.keep = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
@@ -922,22 +920,31 @@ int gate_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_
   return launch_gate_finish(logits, lstride, B, m->graph.cfg.n_experts, probs, expert, counts, lists, stream);
 }
 
-int experts_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_ws, size_t tower_bytes_,
-                 const int32_t* counts, const int32_t* lists, float* normals, hipStream_t stream) {
+// NB = the batch capacity the workspace was laid out for (ws_layout); ecounts = its per-(expert, round) counter block
+int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned char* tower_ws, size_t tower_bytes_,
+                 const int32_t* counts, const int32_t* lists, int32_t* ecounts, float* normals, hipStream_t stream) {
   const int E = m->graph.cfg.n_experts;
+  const int cap = std::min(expert_cap(NB), B), rounds = (B + cap - 1) / cap;
   prof_phase(NESTI_PHASE_EXPERTS);
+  if (counts && launch_round_counts(counts, E, cap, rounds, ecounts, stream)) return 1;
+  const size_t x0_row = ((size_t)1 << (3 * m->graph.gate_x0_log2S())) * mups_stride(m) * dtype_size(m->dtype);   // one query's MuPS rows
   for (int e = 0; e < E; ++e) {
     const Tower& T = m->graph.experts[e];
-    float* out = nullptr;
     const int ostride = T.bufs[T.out_buf].C;
-    if (counts) {   // top-1 routing: only the points whose arg-max is e (test_n_est_w_experts.py:150-152)
-      RunCtx rc{m, B, counts + e, lists + (size_t)e * B, stream};
-      if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
-      if (launch_scatter3(out, ostride, lists + (size_t)e * B, counts + e, B, normals, stream)) return 1;
-    } else {        // reference behaviour: every expert on every point -> [E,B,3]
-      RunCtx rc{m, B, nullptr, nullptr, stream};
-      if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
-      if (launch_scatter3(out, ostride, nullptr, nullptr, B, normals + (size_t)e * B * 3, stream)) return 1;
+    for (int r = 0; r < rounds; ++r) {
+      float* out = nullptr;
+      if (counts) {   // top-1 routing: only the points whose arg-max is e (test_n_est_w_experts.py:150-152), `cap` of them per round
+        const int32_t* list = lists + (size_t)e * B + (size_t)r * cap;
+        const int32_t* cnt = ecounts + e * rounds + r;
+        RunCtx rc{m, cap, cnt, list, stream};
+        if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
+        if (launch_scatter3(out, ostride, list, cnt, cap, normals, stream)) return 1;
+      } else {        // reference behaviour: every expert on every point -> [E,B,3], rows [r * cap, ...) of the batch per round
+        const int take = std::min(cap, B - r * cap);
+        RunCtx rc{m, take, nullptr, nullptr, stream};
+        if (run_tower(rc, T, (const unsigned char*)X0 + (size_t)r * cap * x0_row, tower_ws, tower_bytes_, &out)) return 1;
+        if (launch_scatter3(out, ostride, nullptr, nullptr, take, normals + ((size_t)e * B + (size_t)r * cap) * 3, stream)) return 1;
+      }
     }
   }
   return 0;
@@ -1137,14 +1144,14 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
     lists = (int32_t*)(ws + L.lists);
     if (launch_route(expert_dev, B, m->graph.cfg.n_experts, counts, lists, st)) return 1;
   }
-  return experts_impl(m, mups_dev, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
+  return experts_impl(m, mups_dev, B, B, ws + L.tower, L.total - L.tower, counts, lists, (int32_t*)(ws + L.ecounts), normals_out_dev, st);
 }
 
 // gate -> routing -> experts on a MuPS tensor X0 that already sits in the workspace
 static int forward_tail(const nesti_model_t* m, const void* X0, int B, int NB, unsigned char* ws, const WsLayout& L,
                         float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, hipStream_t st) {
   if (m->graph.cfg.arch == NESTI_ARCH_SINGLE || m->graph.cfg.arch == NESTI_ARCH_MULTI)   // single-tower ablations: the tower's output IS n_pred (test_n_est.py:136-141)
-    return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, nullptr, nullptr, normals_out_dev, st);
+    return experts_impl(m, X0, B, NB, ws + L.tower, L.total - L.tower, nullptr, nullptr, nullptr, normals_out_dev, st);
   float* probs = probs_out_dev ? probs_out_dev : (float*)(ws + L.probs);
   int32_t* expert = expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert);
   int32_t* counts = (int32_t*)(ws + L.counts);
@@ -1152,7 +1159,7 @@ static int forward_tail(const nesti_model_t* m, const void* X0, int B, int NB, u
   if (m->cascade ? gate_cascade(m, X0, B, ws, L, NB, probs, expert, counts, lists, st)
                  : gate_impl(m, X0, B, ws + L.tower, L.total - L.tower, probs, expert, counts, lists, st))
     return 1;
-  return experts_impl(m, X0, B, ws + L.tower, L.total - L.tower, counts, lists, normals_out_dev, st);
+  return experts_impl(m, X0, B, NB, ws + L.tower, L.total - L.tower, counts, lists, (int32_t*)(ws + L.ecounts), normals_out_dev, st);
 }
 
 int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B, void* ws_dev,

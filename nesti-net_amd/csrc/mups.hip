@@ -122,15 +122,15 @@ __device__ __forceinline__ void store20(void* out, size_t row_off, int col0, con
     }
   }
 }
-// zeros in the padding channels of one row: logical columns [pad0, width) -- for the pair modes in each of the three planes
-// of every 64-channel group (cstride is the physical stride, 3 x the logical width)
+// zeros in the padding channels of one row: logical columns [pad0, width) -- for the pair modes in both planes
+// of every 64-channel group (cstride is the physical stride, 2 x the logical width)
 template <int DT>
 __device__ __forceinline__ void zero_pad_row(void* out, size_t row_off, int pad0, int cstride) {
   using E = Elem<DT>;
   typename E::T* o = reinterpret_cast<typename E::T*>(out) + row_off;
   if constexpr (is_x3<DT>) {
     for (int c = 0; c < cstride; ++c) {
-      const int logical = (c / (3 * kSplitGroup)) * kSplitGroup + (c & (kSplitGroup - 1));
+      const int logical = (c / (kPairPlanes * kSplitGroup)) * kSplitGroup + (c & (kSplitGroup - 1));
       if (logical >= pad0) o[c] = 0;
     }
   } else {
@@ -291,7 +291,7 @@ __device__ __forceinline__ void mups_one_scale(MupsShared& sh, Coord coord, int 
 template <int DT>
 __device__ __forceinline__ void mups_zero_pad(void* __restrict__ out, int b, int S, int cstride, int t) {
   const int pad0 = 20 * S;
-  if (pad0 < cstride / (is_x3<DT> ? 3 : 1)) {
+  if (pad0 < cstride / (is_x3<DT> ? kPairPlanes : 1)) {
     const int k = t & 7, j = (t >> 3) & 7, i0 = t >> 6;
     const int g0 = 64 * i0 + 8 * j + k, g1 = g0 + 256;
     zero_pad_row<DT>(out, ((size_t)b * kG + g0) * cstride, pad0, cstride);
@@ -448,9 +448,9 @@ int launch_mups(const nesti_config_t* cfg, const float* points, const int32_t* n
                 void* out, int out_dtype, int out_cstride, int embed4, hipStream_t stream) {
   if (cfg->grid_n != kR && cfg->grid_n != 3) NESTI_FAIL("nesti_mups_forward: the Gaussian grid must be 8^3 or 3^3");
   if (cfg->n_scales < 1 || cfg->n_scales > NESTI_MAX_SCALES) NESTI_FAIL("nesti_mups_forward: bad n_scales");
-  const bool x3 = act_planes(out_dtype) == 3;   // three planes per 64-channel group: out_cstride is the physical stride
-  if (x3 && out_cstride % (3 * kSplitGroup)) NESTI_FAIL("nesti_mups_forward: a bf16x3 row is a whole number of 192-element groups");
-  if (out_cstride / (x3 ? 3 : 1) < 20 * cfg->n_scales || (out_cstride % 4) != 0)
+  const bool x3 = act_planes(out_dtype) > 1;   // two planes per 64-channel group: out_cstride is the physical stride
+  if (x3 && out_cstride % (kPairPlanes * kSplitGroup)) NESTI_FAIL("nesti_mups_forward: a pair-mode row is a whole number of 128-element groups");
+  if (out_cstride / (x3 ? kPairPlanes : 1) < 20 * cfg->n_scales || (out_cstride % 4) != 0)
     NESTI_FAIL("nesti_mups_forward: out_cstride must be >= 20*S and a multiple of 4");
   if (out_dtype != NESTI_F32 && out_dtype != NESTI_BF16 && out_dtype != NESTI_F16 && !x3) NESTI_FAIL("nesti_mups_forward: unknown out_dtype");
   if (B <= 0) return 0;
@@ -496,8 +496,8 @@ int launch_patches_mups(const nesti_config_t* cfg, const float* cloud_dev, int N
                         int out_cstride, int32_t* n_eff_out_dev, hipStream_t stream) {
   if (cfg->grid_n != kR) NESTI_FAIL("launch_patches_mups: the fused kernel serves the 8^3 Gaussian grid");
   if (cfg->points_per_scale < 1 || 2 * cfg->points_per_scale > kListCap) NESTI_FAIL("launch_patches_mups: points_per_scale must be in [1, 512]");
-  const bool x3 = act_planes(out_dtype) == 3;
-  if (out_cstride / (x3 ? 3 : 1) < 20 * cfg->n_scales || (out_cstride % (x3 ? 3 * kSplitGroup : 4)) != 0)
+  const bool x3 = act_planes(out_dtype) > 1;
+  if (out_cstride / (x3 ? kPairPlanes : 1) < 20 * cfg->n_scales || (out_cstride % (x3 ? kPairPlanes * kSplitGroup : 4)) != 0)
     NESTI_FAIL("launch_patches_mups: bad channel stride");
   if (M <= 0) return 0;
   PatchParams p;

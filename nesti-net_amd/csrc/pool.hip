@@ -40,7 +40,7 @@ template <> struct Vec16<NESTI_BF16> : Vec16_16<NESTI_BF16> {};
 template <> struct Vec16<NESTI_F16> : Vec16_16<NESTI_F16> {};
 
 // Pair-mode activations (NESTI_BF16X3 / NESTI_F16X3, common.h): eight logical channels = the hi vector at split_col(col)
-// and the lo vector one 64-element plane further; the value is hi + lo.  Stores emit hi, lo and the second copy of hi.
+// and the lo vector one 64-element plane further; the value is hi + lo.  Stores emit both planes.
 template <int DT>
 __device__ __forceinline__ void load_vec(const unsigned char* base, long long row_elems, int coff, int cv, int split, float* f) {
   using V = Vec16<DT>;
@@ -201,10 +201,11 @@ __global__ void gate_flag_kernel(const float* __restrict__ logits, int lstride, 
   }
 }
 
-// rows [r * cap, r * cap + cap) of the flag list are one recheck round (the f16x3 gate runs on `cap` rows at a time)
-__global__ void round_counts_kernel(const int32_t* __restrict__ flag_count, int cap, int n_rounds, int32_t* __restrict__ out) {
-  const int r = threadIdx.x;
-  if (r < n_rounds) out[r] = max(0, min(cap, *flag_count - r * cap));
+// rows [r * cap, r * cap + cap) of list i are one round of a tower that runs `cap` rows at a time:
+// out[i * n_rounds + r] = how many of them exist (the flag list of the two-stage gate: one list; the routing lists: E)
+__global__ void round_counts_kernel(const int32_t* __restrict__ counts, int n_lists, int cap, int n_rounds, int32_t* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t < n_lists * n_rounds) out[t] = max(0, min(cap, counts[t / n_rounds] - (t % n_rounds) * cap));
 }
 
 // Stage 2 (on the f16x3 gate's logits of one round, compact rows j <-> query flag_list[j]): the final probabilities and
@@ -343,7 +344,14 @@ int launch_gate_flag(const float* logits, int lstride, int B, int E, float tau, 
   hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, stream, flag_count, 1);
   hipLaunchKernelGGL(gate_flag_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, E, tau, probs,
                      expert, keep, flag_count, flag_list, cstat);
-  hipLaunchKernelGGL(round_counts_kernel, dim3(1), dim3(64), 0, stream, flag_count, cap, n_rounds, round_counts);
+  hipLaunchKernelGGL(round_counts_kernel, dim3(1), dim3(64), 0, stream, flag_count, 1, cap, n_rounds, round_counts);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_round_counts(const int32_t* counts, int n_lists, int cap, int n_rounds, int32_t* out, hipStream_t stream) {
+  if (n_lists * n_rounds > 256) NESTI_FAIL("round_counts: too many lists x rounds");
+  hipLaunchKernelGGL(round_counts_kernel, dim3(1), dim3(256), 0, stream, counts, n_lists, cap, n_rounds, out);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

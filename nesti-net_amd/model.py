@@ -16,7 +16,7 @@ from . import _lib
 from .config import ARCH_MULTI, ARCH_SINGLE, DTYPES, NestiConfig
 
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16,
-             "bf16x3": torch.bfloat16, "f16x3": torch.float16,   # pair modes: 16-bit elements, three planes per 64-channel group
+             "bf16x3": torch.bfloat16, "f16x3": torch.float16,   # pair modes: 16-bit elements, two planes [hi | lo] per 64-channel group
              "f16x3c": torch.float16}                            # f16x3 with the two-stage gate (include/nesti_hip.h: NESTI_F16X3C)
 
 

@@ -31,10 +31,10 @@ def worker(B, reps, dtype):
     v[..., 60:] = 0
     if cs == 64:
         mups = v.to(_TORCH_DT[dtype])
-    else:                       # pair layout [hi | lo | hi]
+    else:                       # pair layout [hi | lo]
         hi = v.to(torch.float16)
         lo = (v - hi.float()).to(torch.float16)
-        mups = torch.cat([hi, lo, hi], dim=-1).contiguous()
+        mups = torch.cat([hi, lo], dim=-1).contiguous()
     net.gate(mups)
     torch.cuda.synchronize()
     lib.nesti_profile_enable(1)

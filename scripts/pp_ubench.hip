@@ -1,0 +1,207 @@
+// Micro-benchmark for the conv8_kernel tap loop (round 3): which loop STRUCTURE lets the two waves of a SIMD keep the matrix
+// pipe busy?  One workgroup = 8 waves, 160 KiB LDS (32 KiB weight slots + 128 KiB input chunk), per wave 8 accumulator
+// tiles; a "tap" = for every live tile two v_mfma_f32_32x32x16_f16 (K = 32) fed by two ds_read_b128 A fragments, plus two B
+// fragment reads per tap; a 10-KiB weight row streams in by LDS-DMA every 5 taps (+ barrier), like conv8_kernel<., 5>.
+//   V0  conv8_kernel's structure: one s_waitcnt lgkmcnt(0) per tap, tile j's next-tap fragments read right after its MFMAs
+//   V1  ping-pong: waves 0-3 and 4-7 alternate between a LOAD phase (all 18 reads of the next tap) and a COMPUTE phase
+//       (16 MFMAs, K-step-major), one s_barrier per phase
+//   V2  as V1 but tile-major MFMA order (the two MFMAs of a tile back to back, dependent)
+//   V3  as V1 with both halves in the SAME phase (control: is the alternation what pays?)
+//   V4  interleaved like V0 but every fragment read is unconditional (dead tiles included), only the MFMAs are skipped: the
+//       compiler can then place exact s_waitcnt lgkmcnt(N) per tile instead of a full drain per tap
+// Each with all tiles live and with conv8<5>'s skip pattern (72 % of the tiles live).  Random f16 data (realistic clocks).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4_t* lds_u32x4_ptr;
+__device__ __forceinline__ uint4 lds128(unsigned addr) {
+  const u32x4_t v = *(lds_u32x4_ptr)(size_t)addr;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void mma(f32x16& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void glds16(const unsigned char* src, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+
+constexpr int kAOff = 32768, kTile = 2048;
+
+template <int V, bool SKIP>
+__global__ __launch_bounds__(512) void k(const unsigned char* in, float* out, int taps, const unsigned* masks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  for (int i = tid; i < 163840 / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = reinterpret_cast<const uint4*>(in)[i & 8191];
+  __syncthreads();
+  f32x16 acc[8];
+  for (int j = 0; j < 8; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  uint4 a[8][2], b[2];
+  // conv8_kernel's conflict-free layout: 64-B rows, 16-B slot XOR-swizzled by the point index (A) / (row >> 2) & 3 (B);
+  // the second K-step's fragment sits 32 B above or below the first
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int a_sw = (khalf ^ (l31 >> 3)) & 3, b_sw = (khalf ^ (l31 >> 2)) & 3;
+  const unsigned a_lane = lds0 + kAOff + l31 * 64 + (a_sw << 4);
+  const unsigned b_lane = lds0 + l31 * 64 + (b_sw << 4);
+  const unsigned a_d1 = (a_sw & 2) ? (unsigned)-32 : 32u, b_d1 = (b_sw & 2) ? (unsigned)-32 : 32u;
+  auto tap_mask = [&](int t) -> unsigned {
+    unsigned m = SKIP ? (unsigned)__builtin_amdgcn_readfirstlane((int)masks[(t % 125) * 8 + wave]) : 0xffu;
+    asm volatile("" : "+s"(m));
+    return m;
+  };
+  auto a_base = [&](int t) -> unsigned { return a_lane + (unsigned)(((t * 5 + wave) & 7) * 8 * kTile) + (unsigned)((t % 5) * 64); };
+  auto b_base = [&](int t) -> unsigned { return b_lane + (unsigned)((t % 15) * kTile); };
+  auto stage_row = [&](int row) {                                         // 10 KiB per 5 taps, 3 slots
+    const unsigned char* src = in + (size_t)(row & 7) * 10240;
+    for (int pid = wave; pid < 10; pid += 8) glds16(src + pid * 1024 + lane * 16, lds0 + (row % 3) * 10240 + pid * 1024);
+  };
+  auto load_all = [&](int t, unsigned m, bool uncond) __attribute__((always_inline)) {
+    const unsigned ab = a_base(t), bb = b_base(t);
+    b[0] = lds128(bb);
+    b[1] = lds128(bb + b_d1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (uncond || (m & (1u << j))) {
+        a[j][0] = lds128(ab + j * kTile);
+        a[j][1] = lds128(ab + j * kTile + a_d1);
+      }
+  };
+
+  if (V == 5) {                     // operands stay in registers: the matrix pipe alone (16 MFMAs per tap, no LDS traffic)
+    load_all(0, 0xffu, true);
+    for (int t = 0; t < taps; ++t) {
+      const unsigned m = tap_mask(t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (m & (1u << j)) { mma(acc[j], a[j][0], b[0]); mma(acc[j], a[j][1], b[1]); }
+    }
+  } else if (V == 0 || V == 4) {
+    load_all(0, tap_mask(0), V == 4);
+    for (int t = 0; t < taps; ++t) {
+      if (t % 5 == 0) stage_row(t / 5 + 2);
+      const unsigned m = tap_mask(t), mn = tap_mask(t + 1);
+      const unsigned ab = a_base(t + 1), bb = b_base(t + 1);
+      if (V == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const uint4 b0 = b[0], b1 = b[1];
+      b[0] = lds128(bb);
+      b[1] = lds128(bb + b_d1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (V == 0) {
+          if (m & (1u << j)) { mma(acc[j], a[j][0], b0); mma(acc[j], a[j][1], b1); }
+          if (mn & (1u << j)) { a[j][0] = lds128(ab + j * kTile); a[j][1] = lds128(ab + j * kTile + a_d1); }
+        } else {
+          if (m & (1u << j)) { mma(acc[j], a[j][0], b0); mma(acc[j], a[j][1], b1); }
+          a[j][0] = lds128(ab + j * kTile);
+          a[j][1] = lds128(ab + j * kTile + a_d1);
+        }
+      }
+      if (t % 5 == 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    }
+  } else {
+    // ping-pong: phase p: group X (waves 0-3) loads tap p/2 when p is even and computes it when p is odd; group Y (waves 4-7)
+    // runs one phase behind (V3: not behind)
+    const bool late = (V != 3) && wave >= 4;
+    if (late) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < taps; ++t) {
+      const unsigned m = tap_mask(t);
+      if (t % 5 == 0) stage_row(t / 5 + 2);
+      load_all(t, m, false);
+      if (t % 5 == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      if (V == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (m & (1u << j)) { mma(acc[j], a[j][0], b[0]); mma(acc[j], a[j][1], b[1]); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (m & (1u << j)) mma(acc[j], a[j][0], b[0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (m & (1u << j)) mma(acc[j], a[j][1], b[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    if (!late && V != 3) __builtin_amdgcn_s_barrier();
+  }
+  float s = 0;
+  for (int j = 0; j < 8; ++j) for (int r = 0; r < 16; ++r) s += acc[j][r];
+  out[blockIdx.x * 512 + tid] = s;
+}
+
+template <int V, bool SKIP>
+void run(const char* name, const unsigned char* in, float* out, const unsigned* masks, double live) {
+  const int taps = 4000;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(&k<V, SKIP>), hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<V, SKIP>), dim3(1024), dim3(512), 163840, 0, in, out, taps, masks);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (rep && ms < best) best = ms;
+  }
+  const double mfma = 1024.0 * 8 * taps * 16 * live;
+  printf("V%d %-46s %s: %8.3f ms  %7.1f TFLOP/s issued (pipe busy %.1f %% of 2.5 PF)\n", V, name, SKIP ? "72% live" : "all live",
+         best, mfma * 32768 / (best * 1e-3) / 1e12, mfma * 32768 / (best * 1e-3) / 2.5e15 * 100);
+}
+
+int main(int argc, char** argv) {
+  const int data_mode = argc > 1 ? atoi(argv[1]) : 0;      // 0: random f16, 1: zeros, 2: the constant 0x3c3c (r01's ubench)
+  unsigned char* in; float* out; unsigned* masks;
+  hipMalloc(&in, 1 << 20); hipMalloc(&out, 1024 * 512 * 4); hipMalloc(&masks, 125 * 8 * 4);
+  uint16_t* h = (uint16_t*)malloc(1 << 20);
+  srand(1);
+  for (int i = 0; i < (1 << 19); ++i) {               // random f16 in about [-1, 1]: sign, exponent 11..14, random mantissa
+    h[i] = (uint16_t)(((rand() & 1) << 15) | ((11 + rand() % 4) << 10) | (rand() & 1023));
+    if (data_mode == 1) h[i] = 0;
+    if (data_mode == 2) h[i] = 0x3c3c;
+  }
+  printf("data: %s\n", data_mode == 0 ? "random f16" : data_mode == 1 ? "zeros" : "constant 0x3c3c");
+  hipMemcpy(in, h, 1 << 20, hipMemcpyHostToDevice);
+  unsigned hm[125 * 8];
+  double live = 0;
+  for (int t = 0; t < 125; ++t) {                     // conv8_kernel<., 5>: tile j of wave w is (y = (w - j) & 7, z = j)
+    const int dz = t / 25 - 2, dy = (t / 5) % 5 - 2;
+    for (int w = 0; w < 8; ++w) {
+      unsigned m = 0;
+      for (int j = 0; j < 8; ++j) {
+        const int y = (w - j) & 7, z = j;
+        if ((unsigned)(y + dy) < 8u && (unsigned)(z + dz) < 8u) m |= 1u << j;
+      }
+      hm[t * 8 + w] = m;
+      live += __builtin_popcount(m);
+    }
+  }
+  live /= 125.0 * 64;
+  hipMemcpy(masks, hm, sizeof(hm), hipMemcpyHostToDevice);
+  printf("live fraction of the skip pattern: %.4f\n", live);
+  run<5, false>("registers only (no LDS reads)", in, out, masks, 1.0);
+  run<5, true>("registers only (no LDS reads)", in, out, masks, live);
+  run<0, false>("conv8 structure (drain per tap)", in, out, masks, 1.0);
+  run<1, false>("ping-pong, K-step-major", in, out, masks, 1.0);
+  run<2, false>("ping-pong, tile-major", in, out, masks, 1.0);
+  run<3, false>("same-phase control", in, out, masks, 1.0);
+  run<4, false>("interleaved, unconditional reads", in, out, masks, 1.0);
+  run<0, true>("conv8 structure (drain per tap)", in, out, masks, live);
+  run<1, true>("ping-pong, K-step-major", in, out, masks, live);
+  run<2, true>("ping-pong, tile-major", in, out, masks, live);
+  run<3, true>("same-phase control", in, out, masks, live);
+  run<4, true>("interleaved, unconditional reads", in, out, masks, live);
+  return 0;
+}

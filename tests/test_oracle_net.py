@@ -12,9 +12,13 @@ def test_same_padding_even_and_odd_kernels():
         x = rng.randn(2, 4, 4, 4, 3)
         w = rng.randn(k, k, k, 3, 5)
         b = rng.randn(5)
-        got = N.conv3d_same(torch.as_tensor(x), torch.as_tensor(w), torch.as_tensor(b)).numpy()
         ref = N.naive_conv3d_same(x, w, b)
-        assert np.abs(got - ref).max() < 1e-10, k
+        # the fp64 dispatcher (tap sum for k > 1), both implementations, and the fp32 dispatcher (library convolution)
+        for fn in (N.conv3d_same, N.conv3d_same_taps, N.conv3d_same_direct):
+            got = fn(torch.as_tensor(x), torch.as_tensor(w), torch.as_tensor(b)).numpy()
+            assert np.abs(got - ref).max() < 1e-10, (k, fn.__name__)
+        got32 = N.conv3d_same(torch.as_tensor(x).float(), torch.as_tensor(w).float(), torch.as_tensor(b).float()).numpy()
+        assert np.abs(got32 - ref).max() < 1e-4, k
 
 
 def test_same_padding_k2_is_high_side():
