@@ -192,11 +192,11 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
           f[ni] = *reinterpret_cast<const uint4*>(Bcur + ni * 32 * kRowBytes + b_row + ((slot ^ b_sw) << 4));
       };
       auto mm = [&](const uint4 (&af)[2], const uint4 (&bf)[NI]) __attribute__((always_inline)) {
-        if (KPIPE || live0) {
+        if (KPIPE || __builtin_expect(live0, 1)) {      // the live path falls through: no taken branch per MFMA group
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[0][ni], af[0], bf[ni]);
         }
-        if (KPIPE || live1) {
+        if (KPIPE || __builtin_expect(live1, 1)) {
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[1][ni], af[1], bf[ni]);
         }
@@ -237,11 +237,11 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 3) load_frags(kk + 1, a[(kk + 1) & 1], b[(kk + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of this K-step's MFMAs (hipcc sinks it otherwise)
-      if (KPIPE || live0) {
+      if (KPIPE || __builtin_expect(live0, 1)) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[0][ni], a[kk & 1][0], b[kk & 1][ni]);
       }
-      if (KPIPE || live1) {
+      if (KPIPE || __builtin_expect(live1, 1)) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[1][ni], a[kk & 1][1], b[kk & 1][ni]);
       }

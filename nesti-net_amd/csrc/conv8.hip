@@ -266,7 +266,7 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           if (!last_u) {
-            if (m_mm & (1u << j)) {
+            if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) {
               mma<DT>(acc[j], a[j][0], bc[0]);
               mma<DT>(acc[j], a[j][1], X3 ? bc[0] : bc[1]);
               if (X3) mma<DT>(acc[j], a[j][0], bc[1]);
@@ -274,12 +274,12 @@ __global__ __launch_bounds__(kThreads8) void conv8_kernel(const ConvParams p) {
               a[j][1] = lds128(nb1 + j * kTileBytes);
             }
           } else {
-            if (m_mm & (1u << j)) {
+            if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) {
               mma<DT>(acc[j], a[j][0], bc[0]);
               mma<DT>(acc[j], a[j][1], X3 ? bc[0] : bc[1]);
               if (X3) mma<DT>(acc[j], a[j][0], bc[1]);
             }
-            if (m_rd & (1u << j)) {
+            if (__builtin_expect((m_rd & (1u << j)) != 0, 1)) {
               a[j][0] = lds128(nb0 + j * kTileBytes);
               a[j][1] = lds128(nb1 + j * kTileBytes);
             }
