@@ -1,0 +1,391 @@
+// conv8_kernel with A-fragment reuse: the same k^3-tap conv3d layers on the 8^3 volume (k = 3, 5; conv8.hip has the full
+// story), but a wave owns FOUR x-line tiles x TWO 32-column tiles instead of eight x one, so that every A fragment read from
+// LDS feeds two MFMAs (plain modes) or three + three (pair modes): 0.75 / 0.5 KB of LDS reads per MFMA instead of 1.125 /
+// 0.75.  The time of these kernels follows the LDS bytes per MFMA, not the schedule (scripts/pp_ubench.hip).
+//
+// Workgroup = 4 points x ONE z half of the output volume (z in [4h, 4h + 4)) x 64 output channels.  It stages the
+// NZ = 4 + k/2 source planes that half can reach (6 of 8 for k = 5: 96 KiB instead of 128) and 4 KiB of weights per tap.
+// Tile (y, z) of the half lives with wave (y + z) & 7, as in conv8_kernel, so the four tiles a wave reads for tap
+// (dz, dy) are consecutive slots of wave (w + dy + dz) & 7's run; source plane z' sits at slot NZ * ((y' + z') & 7) + z' - zlo.
+// Waves w and w + 4 (one SIMD) together hold all eight y lines of every z plane of the half: whatever a tap kills, the four
+// matrix pipes lose the same number of tiles.
+//
+// LDS: [0, 64 KiB) weight slots (3 x 20 KiB rows for k = 5, 2 x 24 KiB row pairs for k = 3), [64 KiB, 64 + 16 NZ KiB) the
+// input chunk.  Everything else -- swizzles, LDS-DMA staging, out-of-range reads for the x padding, the one-tap fragment
+// lookahead, the fused 2^3 max-pool epilogue -- is conv8_kernel's.
+#include <type_traits>
+
+#include "kernels.h"
+#include "mma.h"
+
+namespace nesti {
+namespace {
+
+constexpr int kThreadsN = 512;
+constexpr int kPtsN = 4;
+constexpr int kTileN = 2048;                 // 32 rows x 64 B
+constexpr int kBTileN = 2 * kTileN;          // one tap's weights: two 32-column tiles
+constexpr int kAOffN = 65536;
+constexpr unsigned kOobN = 0x40000u;         // beyond any LDS allocation: ds_read returns 0
+constexpr int kEpiStrideN = 144;             // bytes per row of the fp32 [1024][32] epilogue tile (+16 B pad)
+
+typedef unsigned u32x4n_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4n_t* lds_u32x4n_ptr;
+__device__ __forceinline__ uint4 lds128n(unsigned addr) {
+  const u32x4n_t v = *(lds_u32x4n_ptr)(size_t)addr;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+template <int K> constexpr int lds_bytes_n() { return kAOffN + 8 * (4 + (K - 1) / 2) * kTileN; }
+
+template <int DT, int K, bool X3>
+__global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
+  constexpr int LO = (K - 1) / 2;
+  constexpr int NG = K * K;                  // (dz, dy) rows of taps per chunk
+  constexpr int NZ = 4 + LO;                 // staged source planes
+  constexpr int R = (K == 3) ? 2 : 1;        // rows of taps per weight slot (conv8.hip)
+  constexpr int NS = (K == 3) ? 2 : 3;
+  constexpr int AHEAD = NS - 1;
+  constexpr int kSlot = R * K * kBTileN;
+  constexpr int NSR = (NG + R - 1) / R;
+  static_assert(NS * kSlot <= kAOffN, "weight slots must fit below the input chunk");
+  static_assert((K & 1) == 1, "the weight-fragment ping-pong assumes an odd number of taps per row");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // XCD-aware block -> tile map: the 2 halves x n_tiles column pairs of a group of 4 points stay on one XCD's L2
+  const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
+  const int per_m = 2 * p.n_tiles;                       // p.n_tiles = 64-column pairs
+  const int sub = grp % per_m;
+  const int n_pair = sub >> 1, half = sub & 1;
+  const int m_tile = (grp / per_m) * 8 + xcd;
+  if (m_tile >= p.m_tiles) return;
+  int npts = p.npoints;
+  if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
+  const int p0 = m_tile * kPtsN;
+  if (p0 >= npts) return;
+  const int np_here = min(kPtsN, npts - p0);
+  const int z0 = 4 * half;                               // first output plane of this half
+  const int zlo = half ? 8 - NZ : 0;                     // first staged source plane
+
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+  const unsigned char* in_b = reinterpret_cast<const unsigned char*>(p.in) +
+                              ((size_t)p0 * 512 * p.in_cstride + p.in_coff) * kEsz;
+  const unsigned char* w_tile = reinterpret_cast<const unsigned char*>(p.wpk) +
+                                (size_t)n_pair * p.n_chunks * (K * K * K) * kBTileN;
+
+  // ---- A staging: wave w fills the NZ slots of its run; piece h of a tile = rows 16h .. 16h+15 (row = 8 pt + x) ------
+  const int st_row = lane >> 2;
+  unsigned a_voff[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int pt = 2 * h + (st_row >> 3), x = st_row & 7;
+    const int kslot = (lane & 3) ^ pt;                   // inverse swizzle on the SOURCE (LDS-DMA writes lane-linear)
+    a_voff[h] = (unsigned)((pt * 512 + x) * p.in_cstride * kEsz + (X3 ? (kslot & 1) * 16 + (kslot >> 1) * (2 * kSplitGroup) : kslot * 16));
+    a_ok[h] = pt < np_here;
+  }
+  auto stage_a = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int jz = 0; jz < NZ; ++jz) {
+      const int zp = zlo + jz, yp = (wave - zp) & 7;     // source tile (y', z') of this wave's run: (y' + z') & 7 == wave
+      const unsigned char* src = in_b + (size_t)((zp * 64 + yp * 8) * p.in_cstride) * kEsz +
+                                 (X3 ? (size_t)(c >> 2) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 3) * 32 : (size_t)c * 64);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (a_ok[h]) glds16(src + a_voff[h], lds0 + kAOffN + (wave * NZ + jz) * kTileN + h * 1024);
+    }
+  };
+  auto stage_b = [&](int c, int sr, int slot) __attribute__((always_inline)) {   // rows sr * R .. of chunk c
+    const unsigned char* src = w_tile + ((size_t)c * (K * K * K) + (size_t)sr * R * K) * kBTileN;
+    const int pieces = 4 * K * min(R, NG - sr * R);
+    for (int pid = wave; pid < pieces; pid += 8)
+      glds16(src + pid * 1024 + lane * 16, lds0 + slot * kSlot + pid * 1024);
+  };
+
+  // ---- per-lane fragment coordinates ---------------------------------------------------------------------------
+  const int l31 = lane & 31, khalf = lane >> 5;
+  const int pt = l31 >> 3, rx = l31 & 7;
+  const int a_sw = (khalf ^ pt) & 3, b_sw = (khalf ^ (l31 >> 2)) & 3;
+  const unsigned a_lane = lds0 + kAOffN + (unsigned)((pt * 8 + rx) * 64 + (a_sw << 4));
+  const unsigned b_lane = lds0 + (unsigned)(l31 * 64 + (b_sw << 4));
+  const unsigned a_d1 = (a_sw & 2) ? (unsigned)-32 : 32u, b_d1 = (b_sw & 2) ? (unsigned)-32 : 32u;
+
+  // liveness of this wave's tiles: tile j is (y = (wave - z0 - j) & 7, z = z0 + j); 4 bits per dy / per dz
+  unsigned ymask_pack = 0u, zmask_pack = 0u;
+#pragma unroll
+  for (int d = 0; d < K; ++d) {
+    unsigned my = 0, mz = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = (wave - z0 - j) & 7, z = z0 + j;
+      if ((unsigned)(y + d - LO) < 8u) my |= 1u << j;
+      if ((unsigned)(z + d - LO) < 8u) mz |= 1u << j;
+    }
+    ymask_pack |= my << (4 * d);
+    zmask_pack |= mz << (4 * d);
+  }
+  // Per-tap bookkeeping is kept off the critical path (a SIMD's two waves run the same phase between the row barriers, so
+  // every scalar / vector instruction a wave spends between two MFMA groups is matrix-pipe idle time): the (dz, dy) loops
+  // carry their masks, source-run offsets and weight-slot offsets incrementally (no divisions), the x-shifted per-lane read
+  // addresses are K precomputed VGPRs.
+  unsigned pa[K];                                        // per-lane A read address for x shift d - LO, or out of range
+#pragma unroll
+  for (int d = 0; d < K; ++d) pa[d] = ((unsigned)(rx + d - LO) < 8u) ? a_lane + (unsigned)((d - LO) * 64) : kOobN;
+  auto mask_of = [&](int dzi, int dyi) __attribute__((always_inline)) -> unsigned {
+    return (zmask_pack >> (4 * dzi)) & (ymask_pack >> (4 * dyi)) & 0xfu;
+  };
+  // LDS byte offset of the source run of tap row (dz, dy): slots of wave (w + dy + dz) & 7, starting at plane z0 + dz
+  auto base_of = [&](int dzi, int dyi) __attribute__((always_inline)) -> int {
+    return (((wave + dyi + dzi - 2 * LO) & 7) * NZ + (z0 - zlo + dzi - LO)) * kTileN;
+  };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+
+  // b[u & 1] holds tap u's weight fragments [column tile][K-step, or hi / lo]; K is odd, so the last tap of a row leaves the
+  // next row's first set in b[1]: it is moved to b[0] once per row
+  uint4 a[4][2], b[2][2][2];
+  auto load_b = [&](uint4 (&dst)[2][2], unsigned src) __attribute__((always_inline)) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      dst[n][0] = lds128n(src + n * kTileN);
+      dst[n][1] = lds128n(src + n * kTileN + b_d1);
+    }
+  };
+  auto tile_mma = [&](int j, const uint4 (&bc)[2][2]) __attribute__((always_inline)) {
+    if (X3) {   // hi * W_hi, lo * W_hi, hi * W_lo for both column tiles (a[j][0] = hi, a[j][1] = lo; bc[n][0] = W_hi, bc[n][1] = W_lo)
+      mma<DT>(acc[j][0], a[j][0], bc[0][0]);
+      mma<DT>(acc[j][1], a[j][0], bc[1][0]);
+      mma<DT>(acc[j][0], a[j][1], bc[0][0]);
+      mma<DT>(acc[j][1], a[j][1], bc[1][0]);
+      mma<DT>(acc[j][0], a[j][0], bc[0][1]);
+      mma<DT>(acc[j][1], a[j][0], bc[1][1]);
+    } else {
+      mma<DT>(acc[j][0], a[j][0], bc[0][0]);
+      mma<DT>(acc[j][1], a[j][0], bc[1][0]);
+      mma<DT>(acc[j][0], a[j][1], bc[0][1]);
+      mma<DT>(acc[j][1], a[j][1], bc[1][1]);
+    }
+  };
+  // one (dz, dy) row of K taps
+  auto row = [&](unsigned mask_g, unsigned mask_n, int base_g, int base_n, unsigned boff_g, unsigned boff_n,
+                 bool pair_end) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const bool last_u = (u == K - 1);
+      unsigned m_mm = mask_g, m_rd = last_u ? mask_n : mask_g;   // tiles multiplied now / tiles whose next-tap fragments are read
+      asm volatile("" : "+s"(m_mm), "+s"(m_rd));
+      const unsigned nb0 = pa[last_u ? 0 : u + 1] + (unsigned)(last_u ? base_n : base_g);
+      const unsigned nb1 = nb0 + a_d1;
+      const unsigned bsrc = b_lane + (last_u ? boff_n : boff_g + (unsigned)((u + 1) * kBTileN));
+      // ---- top of tap: everything read during the previous tap has landed ---------------------------------------
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (R > 1 && last_u && pair_end) {
+        // shared slots (k = 3): confirm the next pair's weights before this tap prefetches their first fragments, and
+        // free the current slot for the fill the next row starts (conv8.hip)
+        wait_vm0();
+        __builtin_amdgcn_s_barrier();
+      }
+      if (u == 0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) { b[0][n][0] = b[1][n][0]; b[0][n][1] = b[1][n][1]; }
+      }
+      uint4(&bc)[2][2] = b[u & 1];
+      uint4(&bn)[2][2] = b[(u + 1) & 1];
+      if (m_rd) load_b(bn, bsrc);                        // there is a next tap in this chunk
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!last_u) {
+          if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) {
+            tile_mma(j, bc);
+            a[j][0] = lds128n(nb0 + j * kTileN);
+            a[j][1] = lds128n(nb1 + j * kTileN);
+          }
+        } else {
+          if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) tile_mma(j, bc);
+          if (__builtin_expect((m_rd & (1u << j)) != 0, 1)) {
+            a[j][0] = lds128n(nb0 + j * kTileN);
+            a[j][1] = lds128n(nb1 + j * kTileN);
+          }
+        }
+      }
+    }
+    if (R == 1) {
+      wait_vm0();                                        // the next row's weight DMA (issued two rows ago) has landed
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+
+  for (int c = 0; c < p.n_chunks; ++c) {
+    __syncthreads();                       // every wave is done with the previous chunk
+    stage_a(c);
+#pragma unroll
+    for (int sr = 0; sr < AHEAD; ++sr) stage_b(c, sr, sr);
+    wait_vm0();
+    __syncthreads();
+    {                                      // prologue: fragments of tap 0 (row 0, dx = -LO); every row starts by moving b[1] to b[0]
+      const unsigned m0 = mask_of(0, 0);
+      const unsigned nb0 = pa[0] + (unsigned)base_of(0, 0);
+      const unsigned nb1 = nb0 + a_d1;
+      load_b(b[1], b_lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (m0 & (1u << j)) {
+          a[j][0] = lds128n(nb0 + j * kTileN);
+          a[j][1] = lds128n(nb1 + j * kTileN);
+        }
+    }
+    // row g = (dzi, dyi); its weights sit at LDS offset boff; the fill that keeps AHEAD slot fills in flight goes to `fslot`
+    int dzi = 0, dyi = 0, fill = AHEAD, fslot = AHEAD % NS;
+    unsigned boff = 0u;
+    for (int g = 0; g < NG; ++g) {
+      if (g % R == 0 && fill < NSR) {      // g % R: R is 1 or 2
+        stage_b(c, fill, fslot);
+        ++fill;
+        fslot = (fslot + 1 == NS) ? 0 : fslot + 1;
+      }
+      const bool more = g + 1 < NG;
+      int dzn = dzi, dyn = dyi + 1;
+      if (dyn == K) { dyn = 0; ++dzn; }
+      // next row's weights: the second half of this slot (k = 3, first row of a pair) or the start of the next slot
+      unsigned boff_n = (R > 1 && (g & 1) == 0) ? boff + (unsigned)(K * kBTileN) : (boff - (boff % kSlot)) + kSlot;
+      if (boff_n >= (unsigned)(NS * kSlot)) boff_n = 0u;
+      const unsigned mask_g = mask_of(dzi, dyi), mask_n = more ? mask_of(dzn, dyn) : 0u;
+      const int base_g = base_of(dzi, dyi), base_n = more ? base_of(dzn, dyn) : 0;
+      const bool pair_end = (g % R == R - 1) || !more;
+      row(mask_g, mask_n, base_g, base_n, boff, boff_n, pair_end);
+      dzi = dzn; dyi = dyn; boff = boff_n;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __syncthreads();                                       // nobody still reads A / B: the LDS becomes the epilogue tile
+
+  // ---- epilogue: bias + ReLU in fp32 through an LDS tile [4 pts x 256 voxels of the half][32], one pass per column tile --
+  const int out_esz = p.out_f32 ? 4 : kEsz;
+  const float act_floor = p.relu ? 0.f : -INFINITY;
+  unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
+  unsigned char* mp_b = reinterpret_cast<unsigned char*>(p.mp_out);
+  auto cvt_store8 = [&](unsigned char* base, long long row_elems, int col, const float4& f0, const float4& f1) __attribute__((always_inline)) {
+    if (out_esz == 4) {
+      float4* dst = reinterpret_cast<float4*>(base + (row_elems + col) * 4);
+      dst[0] = f0;
+      dst[1] = f1;
+    } else {
+      using E = Elem<DT == NESTI_F32 ? NESTI_BF16 : DT>;
+      store_act8<E>(base, row_elems, col, f0, f1, p.split);
+    }
+  };
+  auto epi_pass = [&](auto NN) __attribute__((always_inline)) {
+    constexpr int n = decltype(NN)::value;
+    const int n_tile = 2 * n_pair + n;
+    const float bv = p.bias[n_tile * 32 + l31];
+    const int out_col0 = p.out_coff + n_tile * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                        // z = z0 + j, y = (wave - z0 - j) & 7
+      const int y = (wave - z0 - j) & 7;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;      // MFMA row = 8 pt + x
+        const int row = ((((m >> 3) * 4 + j) * 8 + y) << 3) + (m & 7);
+        *reinterpret_cast<float*>(smem + row * kEpiStrideN + l31 * 4) = fmaxf(fmaf(acc[j][n][r], p.acc_scale, bv), act_floor);
+      }
+    }
+    __syncthreads();
+    if (p.mp_mode != 1) {                                // full-resolution rows: 4 lanes x 8 channels = one 32-channel row segment
+#pragma unroll 2
+      for (int it = 0; it < 8; ++it) {
+        const int item = it * kThreadsN + tid;
+        const int row = item >> 2, seg = item & 3;
+        const int ptl = row >> 8, vox = z0 * 64 + (row & 255);
+        if (ptl < np_here) {
+          const float4 f0 = *reinterpret_cast<const float4*>(smem + row * kEpiStrideN + seg * 32);
+          const float4 f1 = *reinterpret_cast<const float4*>(smem + row * kEpiStrideN + seg * 32 + 16);
+          cvt_store8(out_b, ((long long)(p0 + ptl) * 512 + vox) * p.out_cstride, out_col0 + seg * 8, f0, f1);
+        }
+      }
+    }
+    if (p.mp_mode != 0) {                                // fused 2^3 / 2 max-pool of the activated values: 4 pts x 2 x 4 x 4 cells
+      const int cell = tid >> 2, seg = tid & 3;          // 128 cells x 4 segments of 8 channels
+      const int ptl = cell >> 5, cz = (cell >> 4) & 1, cy = (cell >> 2) & 3, cx = cell & 3;
+      float4 m0 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), m1 = m0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = ((ptl * 4 + 2 * cz + (q >> 2)) * 8 + 2 * cy + ((q >> 1) & 1)) * 8 + 2 * cx + (q & 1);
+        const float4 f0 = *reinterpret_cast<const float4*>(smem + row * kEpiStrideN + seg * 32);
+        const float4 f1 = *reinterpret_cast<const float4*>(smem + row * kEpiStrideN + seg * 32 + 16);
+        m0.x = fmaxf(m0.x, f0.x); m0.y = fmaxf(m0.y, f0.y); m0.z = fmaxf(m0.z, f0.z); m0.w = fmaxf(m0.w, f0.w);
+        m1.x = fmaxf(m1.x, f1.x); m1.y = fmaxf(m1.y, f1.y); m1.z = fmaxf(m1.z, f1.z); m1.w = fmaxf(m1.w, f1.w);
+      }
+      if (ptl < np_here) {
+        const int ovox = ((2 * half + cz) * 4 + cy) * 4 + cx;
+        cvt_store8(mp_b, ((long long)(p0 + ptl) * 64 + ovox) * p.mp_cstride, out_col0 + seg * 8, m0, m1);
+      }
+    }
+    __syncthreads();
+  };
+  epi_pass(std::integral_constant<int, 0>{});
+  epi_pass(std::integral_constant<int, 1>{});
+}
+
+template <int DT, int K, bool X3>
+int launch_conv8n_one(const ConvParams& p, hipStream_t stream) {
+  constexpr int kMaxDevices = 64;
+  static bool attr_set[kMaxDevices] = {};
+  int dev = 0;
+  NESTI_CHECK_HIP(hipGetDevice(&dev));
+  constexpr int lds = lds_bytes_n<K>();
+  static_assert(lds <= 163840 && 1024 * kEpiStrideN <= lds, "LDS budget");
+  if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
+    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8n_kernel<DT, K, X3>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
+  }
+  const int groups = (p.m_tiles + 7) / 8;
+  dim3 grid((unsigned)(groups * 8 * 2 * p.n_tiles)), block(kThreadsN);
+  hipLaunchKernelGGL((conv8n_kernel<DT, K, X3>), grid, block, lds, stream, p);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int DT>
+int launch_conv8n_dt(const ConvParams& p, int k, hipStream_t stream) {
+  if constexpr (DT != NESTI_F32) {
+    if (p.x3native && k == 5) return launch_conv8n_one<DT, 5, true>(p, stream);
+    if (p.x3native && k == 3) return launch_conv8n_one<DT, 3, true>(p, stream);
+  }
+  if (p.x3native) NESTI_FAIL("launch_conv8n: the pair K loop is for the 16-bit kernels");
+  if (k == 5) return launch_conv8n_one<DT, 5, false>(p, stream);
+  if (k == 3) return launch_conv8n_one<DT, 3, false>(p, stream);
+  NESTI_FAIL("launch_conv8n: kernel size must be 3 or 5");
+}
+
+}  // namespace
+
+// p.m_tiles = groups of 4 points, p.n_tiles = 64-column tile PAIRS, p.n_chunks = 64-byte K chunks, weights packed
+// [pair][chunk][tap][2 x 32 rows][64 B]
+int launch_conv8n(const ConvParams& p, int dtype, int k, hipStream_t stream) {
+  if (p.m_tiles <= 0 || p.n_tiles <= 0) return 0;
+  if (p.log2S != 3 || p.s_real) NESTI_FAIL("launch_conv8n: the 8^3 volume only");
+  if (p.n_taps != k * k * k) NESTI_FAIL("launch_conv8n: all k^3 taps must be present");
+  if (p.point_index) NESTI_FAIL("launch_conv8n: no input gather (k^3 layers never read the routed MuPS tensor)");
+  if (p.pool_k > 1 || p.split_tile != p.n_tiles) NESTI_FAIL("launch_conv8n: no fused avg-pool / merged layers");
+  if (p.mp_mode == 2) NESTI_FAIL("launch_conv8n: max-pool mode 2 is conv1's (a 1x1x1 layer)");
+  if (p.mp_mode != 0 && !p.mp_out) NESTI_FAIL("launch_conv8n: fused max-pool needs an output");
+  if (dtype == NESTI_BF16) return launch_conv8n_dt<NESTI_BF16>(p, k, stream);
+  if (dtype == NESTI_F16) return launch_conv8n_dt<NESTI_F16>(p, k, stream);
+  if (dtype == NESTI_F32) return launch_conv8n_dt<NESTI_F32>(p, k, stream);
+  NESTI_FAIL("launch_conv8n: unsupported dtype");
+}
+
+}  // namespace nesti

@@ -61,6 +61,9 @@ int launch_conv(const ConvParams& p, int dtype, int TN, hipStream_t stream);
 // k^3 taps (k = 3, 5) on the 8^3 volume, four points per workgroup (conv8.hip): p.m_tiles = groups of 4 points,
 // p.n_tiles = 32-column tiles, p.n_chunks = 64-byte K chunks, weights packed [n tile][chunk][tap][32][64 B]
 int launch_conv8(const ConvParams& p, int dtype, int k, hipStream_t stream);
+// the same layers with A-fragment reuse (conv8n.hip): a workgroup = 4 points x one z half x 64 columns; p.n_tiles = 64-column
+// pairs, weights packed [pair][chunk][tap][2 x 32 rows][64 B]
+int launch_conv8n(const ConvParams& p, int dtype, int k, hipStream_t stream);
 
 struct PoolParams {
   const void* in;

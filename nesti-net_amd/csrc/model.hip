@@ -428,7 +428,8 @@ struct PackedLayer {
   void* wpk = nullptr;
   float* bias = nullptr;
   int TN = 64, n_tiles = 0, split_tile = 0, n_chunks = 0, n_taps = 0;
-  int kind = 0;              // 0: conv_igemm_kernel (conv.hip), 1: conv8_kernel (conv8.hip: 4 points per workgroup)
+  int kind = 0;              // 0: conv_igemm_kernel (conv.hip), 1: conv8_kernel (conv8.hip: 4 points per workgroup),
+                             // 2: conv8n_kernel (conv8n.hip: 4 points x a z half x 64 columns per workgroup)
   bool x3n = false;          // pair modes on conv8_kernel: 16-channel K chunks [hi | lo] / [W_hi | W_lo], three MFMAs per fragment set
   float acc_scale = 1.0f;    // 2^-s when the packed weights carry a 2^s scale (NESTI_F16X3)
   int8_t tap[kMaxTaps][4];
@@ -579,13 +580,15 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
   // plain chunk holds (the kernels' pair K loop multiplies hi*W_hi + lo*W_hi + hi*W_lo from it: conv.hip / conv8.hip, X3)
   const int planes = act_planes(dtype);
   const int drop = planes > 1 ? x3_drop_mask(d) : 0;
-  pl->kind = use_conv8(d) ? 1 : 0;
+  // NESTI_CONV8N=0: the 8^3 tap layers on conv8_kernel (one 32-column tile per wave) instead of conv8n_kernel (same-box A/B)
+  static const bool conv8n = [] { const char* e = getenv("NESTI_CONV8N"); return e ? atoi(e) != 0 : true; }();
+  pl->kind = use_conv8(d) ? (conv8n && d.Cout_p % 64 == 0 ? 2 : 1) : 0;
   pl->x3n = planes > 1;
   const int K_phys = d.Cin_p * planes;
-  const int row_bytes = pl->kind == 1 ? 64 : kRowBytes;   // bytes of one K chunk of one row
+  const int row_bytes = pl->kind >= 1 ? 64 : kRowBytes;   // bytes of one K chunk of one row
   const int KC = row_bytes / (int)esz;
   const int chunk_ch = KC / planes;                       // input channels per K chunk
-  pl->TN = pl->kind == 1 ? 32 : (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
+  pl->TN = pl->kind == 1 ? 32 : pl->kind == 2 ? 64 : (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
   pl->n_tiles = d.Cout_p / pl->TN;
   pl->split_tile = part_p / pl->TN * (n_parts == 2 ? 1 : n_parts);
   if (n_parts == 1) pl->split_tile = pl->n_tiles;
@@ -641,7 +644,7 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
             if (n >= d.cout) break;
             const float v = wrow[n] * f.scale[n] * wmul;
             // the kernels' LDS image: row nl, 16-B slot XOR-swizzled (conv8_kernel: 64-B rows, key (row >> 2) & 3)
-            unsigned char* dst = pl->kind == 1
+            unsigned char* dst = pl->kind >= 1
                 ? tile + (size_t)nl * 64 + ((slot ^ ((nl >> 2) & 3)) << 4) + within * esz
                 : tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
             if (dtype == NESTI_F32) memcpy(dst, &v, 4);
@@ -752,7 +755,7 @@ int conv_remap(int k, int log2S, int n_taps) {
 
 // which NESTI_PROF_* conv category a layer's launch is booked under
 int conv_category(const LayerDesc& d, const PackedLayer& pl) {
-  if (pl.kind == 1) return d.k == 5 ? NESTI_PROF_CONV8_K5 : NESTI_PROF_CONV8_K3;
+  if (pl.kind >= 1) return d.k == 5 ? NESTI_PROF_CONV8_K5 : NESTI_PROF_CONV8_K3;
   return pl.n_taps > 1 ? NESTI_PROF_TAPS : NESTI_PROF_ONE_BY_ONE;
 }
 
@@ -794,7 +797,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S; p.s_real = d.s_real;
       p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0; p.acc_scale = pl.acc_scale; p.x3native = pl.x3n ? 1 : 0;
       const long long rows = (long long)rc.NB << (3 * d.log2S);
-      p.m_tiles = pl.kind == 1 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
+      p.m_tiles = pl.kind >= 1 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
       if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C * planes; p.mp_mode = op.mp_mode; p.mp_mode2 = op.mp_mode2; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
@@ -805,8 +808,9 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       }
       const int cat = conv_category(d, pl);
       const int tok = prof_begin(cat, rc.stream);
-      const int rcv = pl.kind == 1 ? launch_conv8(p, kernel_dtype(dtype), d.k, rc.stream)
-                                   : launch_conv(p, kernel_dtype(dtype), pl.TN, rc.stream);
+      const int rcv = pl.kind == 2   ? launch_conv8n(p, kernel_dtype(dtype), d.k, rc.stream)
+                      : pl.kind == 1 ? launch_conv8(p, kernel_dtype(dtype), d.k, rc.stream)
+                                     : launch_conv(p, kernel_dtype(dtype), pl.TN, rc.stream);
       prof_end(cat, tok, rc.stream);
       if (rcv) return 1;
     } else {
@@ -1347,7 +1351,7 @@ int nesti_model_macs(const nesti_model_t* m, int tower, int kind, double* nomina
     // (y, z) per 32-row tile and skip it when y + dy or z + dz leaves the volume; elsewhere every kept tap is issued in full
     double tap_sum = pl.n_taps;
     const int Si = 1 << d.log2S;
-    if (pl.n_taps > 1 && (pl.kind == 1 || (d.log2S == 2 && conv_remap(d.k, d.log2S, pl.n_taps)))) {
+    if (pl.n_taps > 1 && (pl.kind >= 1 || (d.log2S == 2 && conv_remap(d.k, d.log2S, pl.n_taps)))) {
       tap_sum = 0;
       for (int t = 0; t < pl.n_taps; ++t)
         tap_sum += (double)std::max(0, S - abs(pl.tap[t][0])) * std::max(0, S - abs(pl.tap[t][1])) / ((double)Si * Si);

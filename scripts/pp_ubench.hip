@@ -22,9 +22,18 @@ __device__ __forceinline__ uint4 lds128(unsigned addr) {
   const u32x4_t v = *(lds_u32x4_ptr)(size_t)addr;
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+#ifdef ACC_AGPR
+// accumulators pinned to the AGPR half of the unified register file (the "a" constraint): the MFMA's C / D traffic then
+// does not share ArchVGPR ports with the LDS returns and the A / B operand reads
+__device__ __forceinline__ void mma(f32x16& acc, const uint4& a, const uint4& b) {
+  const f16x8 av = __builtin_bit_cast(f16x8, a), bv = __builtin_bit_cast(f16x8, b);
+  asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv));
+}
+#else
 __device__ __forceinline__ void mma(f32x16& acc, const uint4& a, const uint4& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
 }
+#endif
 __device__ __forceinline__ void glds16(const unsigned char* src, unsigned lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"

@@ -65,6 +65,20 @@ def test_bench_two_ranks_debug_single_device(gpu_device):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["points_per_cloud"] == 6000 and sum(d["config"]["routing_histogram"]) == 6000
     assert d["parity"]["queries"] == 3000 and d["parity"]["one_minus_cos"]["p50"] <= 2e-5
+    # the strong-scaling leg: ONE cloud's rows over the two ranks (dist.estimate_sharded), printed next to the weak figure
+    assert d["strong"]["scaling"] == "strong" and d["strong"]["value"] > 0 and "ONE 6000-point cloud" in d["strong"]["workload"]
+    assert d["dtype"] == "f16x3c" and d["parity"]["meets_north_star"] and d["gate_cascade"]["rechecked"] > 0
+
+
+def test_bench_strong_leg_at_one_gpu_equals_the_weak_figure(gpu_device):
+    """--strong at N = 1: one cloud over one rank is the headline workload itself, so the two values must agree (VERDICT r02
+    item 7: within a few per cent -- the strong leg times 2 steps, the main run 1)."""
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--points", "20000", "--strong",
+           "--no-cpu-baseline", "--no-secondary", "--no-parity"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and abs(d["strong"]["value"] / d["value"] - 1) < 0.05, (d["value"], d["strong"]["value"])
 
 
 def test_second_device_in_one_process(gpu_device):
