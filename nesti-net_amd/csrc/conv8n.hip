@@ -13,6 +13,8 @@
 // LDS: [0, 64 KiB) weight slots (3 x 20 KiB rows for k = 5, 2 x 24 KiB row pairs for k = 3), [64 KiB, 64 + 16 NZ KiB) the
 // input chunk.  Everything else -- swizzles, LDS-DMA staging, out-of-range reads for the x padding, the one-tap fragment
 // lookahead, the fused 2^3 max-pool epilogue -- is conv8_kernel's.
+#include <string.h>
+
 #include <type_traits>
 
 #include "kernels.h"
@@ -370,7 +372,51 @@ int launch_conv8n_dt(const ConvParams& p, int k, hipStream_t stream) {
   NESTI_FAIL("launch_conv8n: kernel size must be 3 or 5");
 }
 
+// reads 16 B at kOobN from a workgroup that allocated `lds` bytes of dynamic LDS filled with a non-zero pattern
+__global__ void lds_oob_probe_kernel(unsigned* out, unsigned lds) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  for (unsigned i = threadIdx.x; i < lds / 4; i += blockDim.x) reinterpret_cast<unsigned*>(smem)[i] = 0xA5A50000u + i;
+  __syncthreads();
+  const uint4 v = lds128n(kOobN + 16u * threadIdx.x);
+  const uint4 w = lds128n((unsigned)(size_t)(lptr_t)smem + 16u * threadIdx.x);      // in range: must read the pattern back
+  atomicOr(&out[0], v.x | v.y | v.z | v.w);
+  atomicOr(&out[1], w.x == 0xA5A50000u + 4u * threadIdx.x ? 0u : 1u);
+}
+
 }  // namespace
+
+int conv8_selftest() {
+  constexpr int kMaxDevices = 64;
+  static int state[kMaxDevices] = {};          // 0: not run, 1: passed, 2: failed
+  int dev = 0;
+  NESTI_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return 0;
+  if (state[dev] == 1) return 0;
+  if (state[dev] == 0) {
+    hipDeviceProp_t prop;
+    NESTI_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      state[dev] = 2;
+    } else {
+      unsigned* d = nullptr;
+      unsigned h[2] = {1u, 1u};
+      NESTI_CHECK_HIP(hipMalloc((void**)&d, 8));
+      NESTI_CHECK_HIP(hipMemset(d, 0, 8));
+      for (unsigned lds : {65536u, 147456u, 163840u}) {
+        NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_oob_probe_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(lds_oob_probe_kernel, dim3(1), dim3(256), lds, 0, d, lds);
+      }
+      NESTI_CHECK_HIP(hipMemcpy(h, d, 8, hipMemcpyDeviceToHost));
+      (void)hipFree(d);
+      state[dev] = (h[0] == 0u && h[1] == 0u) ? 1 : 2;
+    }
+  }
+  if (state[dev] == 2)
+    NESTI_FAIL("this device is not a gfx950 whose out-of-range LDS reads return zero: the 8^3 tap kernels (conv8.hip, conv8n.hip) "
+               "take their x padding from such reads and would compute wrong convolutions here");
+  return 0;
+}
 
 // p.m_tiles = groups of 4 points, p.n_tiles = 64-column tile PAIRS, p.n_chunks = 64-byte K chunks, weights packed
 // [pair][chunk][tap][2 x 32 rows][64 B]

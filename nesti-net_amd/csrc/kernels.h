@@ -64,6 +64,10 @@ int launch_conv8(const ConvParams& p, int dtype, int k, hipStream_t stream);
 // the same layers with A-fragment reuse (conv8n.hip): a workgroup = 4 points x one z half x 64 columns; p.n_tiles = 64-column
 // pairs, weights packed [pair][chunk][tap][2 x 32 rows][64 B]
 int launch_conv8n(const ConvParams& p, int dtype, int k, hipStream_t stream);
+// conv8_kernel / conv8n_kernel read the x padding from an LDS address beyond the workgroup's allocation and rely on the
+// hardware returning zeros there (gfx950 does: scripts/lds_oob_probe.hip).  Checked once per device, at model creation:
+// the device must be gfx950 and a probe kernel must read zeros; otherwise the model is refused (returns 1 with a message).
+int conv8_selftest();
 
 struct PoolParams {
   const void* in;

@@ -1045,6 +1045,7 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
   dtype = main_dtype(dtype);
   m->dtype = dtype;
   if (build_graph(cfg, &m->graph)) return 1;
+  if (conv8_selftest()) return 1;   // the 8^3 tap kernels' x padding relies on out-of-range LDS reads returning zero
   TensorTable tt;
   for (int i = 0; i < n_tensors; ++i) if (tensors[i].name) tt.by_name[tensors[i].name] = &tensors[i];
   m->packed.resize(m->graph.layers.size());
@@ -1293,8 +1294,10 @@ int nesti_estimate_normals_multi(const nesti_model_t* m, const nesti_shape_queri
       if (take > 0 &&
           launch_patches_mups(cfg, it.cloud_dev, it.n_points, it.query_idx_dev ? it.query_idx_dev + item_done : nullptr, take,
                               it.r_abs, it.seed, it.query_row0 + item_done, it.grid_ws_dev, X0 + (size_t)fill * row_bytes,
-                              m->dtype, mups_stride(m), nullptr, st))
+                              m->dtype, mups_stride(m), nullptr, st)) {
+        prof_end(NESTI_PROF_MUPS, tok, st);      // close the timing span on the error path too
         return 1;
+      }
       fill += take;
       item_done += take;
       if (item_done >= it.n_queries) { ++item; item_done = 0; }

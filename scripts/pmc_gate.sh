@@ -1,11 +1,13 @@
 #!/bin/bash
-# SQ counters of the gating tower's conv launches (last repetition) at batch $1; extra env as $2 (e.g. NESTI_CONV_REMAP=0)
+# SQ counters of the gating tower's conv launches (last repetition) at batch $1; extra env as $2 (e.g. NESTI_CONV8N=0, or "" );
+# dtype as $3 (f16 / f16x3 / bf16 ...)
 cd /tmp && export TMPDIR=/tmp
 B=${1:-2048}
+DT=${3:-f16}
 [ -n "$2" ] && export $2
 out=/tmp/pg_$RANDOM
-rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/scripts/prof_gate.py $B 2 > $out.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d ${out}b -- python3 $GRAFT_REPO_ROOT/scripts/prof_gate.py $B 2 > ${out}b.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $out -- python3 $GRAFT_REPO_ROOT/scripts/prof_gate.py $B 2 $DT > $out.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d ${out}b -- python3 $GRAFT_REPO_ROOT/scripts/prof_gate.py $B 2 $DT > ${out}b.log 2>&1
 python3 - $out ${out}b <<'PY'
 import csv, sys, glob, collections
 def load(d):

@@ -12,11 +12,11 @@ import sys
 root, queries, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 dtype = sys.argv[4] if len(sys.argv) > 4 else "f16"
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else 25000
-DT = {"f32": "0", "bf16": "1", "f16": "2"}[dtype]
+DT = {"f32": "0", "bf16": "1", "f16": "2", "f16x3": "2", "f16x3c": "2", "bf16x3": "1"}[dtype]     # the kernels' element type
 
 
 def family(k):
-    m = re.search(r"(conv8_kernel|conv_igemm_kernel|mups_kernel|maxpool2_kernel)<(\d)", k)
+    m = re.search(r"(conv8n_kernel|conv8_kernel|conv_igemm_kernel|mups_kernel|maxpool2_kernel)<(\d)", k)
     if m:
         if m.group(2) != DT:
             return None
@@ -43,7 +43,7 @@ f, nf = load("FETCH_SIZE")
 w, nw = load("WRITE_SIZE")
 res = {"queries": queries, "dtype": dtype, "batch": batch, "calibrated_gate": True,
        "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity --no-secondary under rocprofv3 --pmc (one pass over the cloud)",
-       "note": "FETCH_SIZE doubled per the gfx950 correction; units KiB -> bytes; 'conv' = conv8_kernel + conv_igemm_kernel", "kernels": {}}
+       "note": "FETCH_SIZE doubled per the gfx950 correction; units KiB -> bytes; 'conv' = conv8n_kernel + conv8_kernel + conv_igemm_kernel (f16x3c: includes the gate-margin calibration's 1024-query double pass, ~1 %)", "kernels": {}}
 for k in sorted(set(f) | set(w)):
     rd, wr = 2.0 * f[k] * 1024, w[k] * 1024
     res["kernels"][k] = {"launches": nf[k], "hbm_read_bytes": rd, "hbm_write_bytes": wr,
