@@ -4,6 +4,10 @@
    gate-cascade margin is derived from (f16-vs-exact logit error against the top-2 margin).
 2. Sweep: the f16x3 model with ONE layer group at a time computed as plain f16 (NESTI_X3_PLAIN, model.hip: the lo * W_hi
    and hi * W_lo weight planes of the matching layers are packed as zeros), 10 240 strided queries against the f32 mode.
+   NOTE: the committed results (profiles/r03_attribution_sweep.txt) were produced at commit 6f246d7, whose pair modes ran
+   three activation planes [hi | lo | hi] against weights [W_hi ; W_hi ; W_lo] -- there each product has its own weight
+   plane and can be switched off.  The two-plane layout of later commits only keeps the hi * W_lo switch (W_lo packed as
+   zeros), so on those this script measures the weight-rounding share alone (":1" / ":2" suffixes are ignored).
 3. Gate / experts time split in f16 and f16x3 on 32 768 queries.
 Prints JSON lines; -> gpurun_out/attr_sweep.txt"""
 import json
