@@ -26,6 +26,17 @@ def family(k):
     return "other"
 
 
+def klass(k):
+    """conv launches by kernel class and K loop: conv8 5^3 / 3^3, taps (igemm, several taps), 1x1 + FC (igemm, one tap)."""
+    m = re.search(r"conv8n?_kernel<(\d), (\d), (true|false)", k)
+    if m:
+        return "conv8_k%s%s" % (m.group(2), "_pair" if m.group(3) == "true" else "")
+    m = re.search(r"conv_igemm_kernel<(\d), \d+, (true|false), (true|false)", k)
+    if m:
+        return ("one_by_one_fc" if m.group(2) == "true" else "taps_4_2") + ("_pair" if m.group(3) == "true" else "")
+    return None
+
+
 def load(c):
     d, n = collections.defaultdict(float), collections.defaultdict(int)
     for r in csv.DictReader(open("%s/pmc_%s/p_counter_collection.csv" % (root, c))):
@@ -36,6 +47,9 @@ def load(c):
             continue
         d[key] += float(r["Counter_Value"])
         n[key] += 1
+        if key == "conv" and klass(r["Kernel_Name"]):
+            d["conv:" + klass(r["Kernel_Name"])] += float(r["Counter_Value"])
+            n["conv:" + klass(r["Kernel_Name"])] += 1
     return d, n
 
 
