@@ -158,3 +158,23 @@ def test_python_enums_follow_the_header():
     for py, name in (("ARCH_EXPERTS", "NESTI_ARCH_EXPERTS"), ("ARCH_SINGLE", "NESTI_ARCH_SINGLE"),
                      ("ARCH_MULTI", "NESTI_ARCH_MULTI"), ("ARCH_SWITCH", "NESTI_ARCH_SWITCH")):
         assert getattr(config, py) == enums[name], py
+
+
+def test_tower_workspace_bytes_from_the_configuration_alone():
+    """nesti_tower_workspace_bytes needs no device: the pair modes keep two planes per 64-channel group (2x the 16-bit
+    footprint), the f16x3c gate figure is the f16 filter pass's, and sizes scale linearly with the batch."""
+    import ctypes
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import _lib
+    from nesti_net_amd.config import DTYPES, NestiConfig
+    lib, c = _lib.load(), NestiConfig().to_c()
+
+    def ws(dtype, tower, batch=1024):
+        return lib.nesti_tower_workspace_bytes(ctypes.byref(c), DTYPES[dtype], tower, batch)
+
+    for tower in (-1, 0, 6):
+        assert ws("f16", tower) > 0 and ws("f16x3", tower) == 2 * ws("f16", tower) and ws("bf16", tower) == ws("f16", tower)
+        assert ws("f16", tower, 2048) == 2 * ws("f16", tower, 1024)
+    assert ws("f16x3c", -1) == ws("f16", -1) and ws("f16x3c", 0) == ws("f16x3", 0)
+    assert 1.5e6 < ws("f16", -1) / 1024 < 2.5e6                      # ~2 MB per query for the gating net in 16-bit
+    assert ws("f16", 7) == 0 and ws("f16", -2) == 0 and ws("f16", 0, 0) == 0

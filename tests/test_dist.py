@@ -125,3 +125,39 @@ def test_gather_two_ranks_gloo(n_rows):
         assert np.array_equal(n, np.stack([rows, rows * 2, rows * 3], 1))
         assert np.array_equal(e, (np.arange(n_rows) % 7).astype(np.int32))      # int32 survives the f32 bit-cast
         assert np.array_equal(p[:, 3], rows + 3)
+
+
+def _worker_alias(rank, world, port, q):
+    import sys
+    sys.path.insert(0, REPO)
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import dist as nd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_rows = 1000                                         # equal shards: the receive buffer itself is handed back
+    lo, hi = nd.shard_range(n_rows, rank, world)
+    first = torch.arange(lo, hi, dtype=torch.float32)[:, None] * torch.tensor([1.0, 2.0, 3.0])
+    a, _, _ = nd.gather_shards(first, None, None, n_rows)            # single-tower model: normals only
+    keep = a.clone()
+    b, _, _ = nd.gather_shards(first + 7.0, None, None, n_rows)      # same shape, different data, same cached buffers
+    q.put((rank, bool(torch.equal(a, keep)), bool(torch.equal(b, keep + 7.0))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_tower_gather_does_not_alias_the_cached_buffer():
+    """with no expert / probs columns the [.., 0:3] slice of the receive buffer is already contiguous, so
+    .contiguous() returned a view of the cached buffer and the next gather of the same shape overwrote results the caller
+    still held."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_alias, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, first_unchanged, second_right in res:
+        assert first_unchanged and second_right, rank
