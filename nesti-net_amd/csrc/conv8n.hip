@@ -189,11 +189,11 @@ __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
       const unsigned nb0 = pa[last_u ? 0 : u + 1] + (unsigned)(last_u ? base_n : base_g);
       const unsigned nb1 = nb0 + a_d1;
       const unsigned bsrc = b_lane + (last_u ? boff_n : boff_g + (unsigned)((u + 1) * kBTileN));
-      // ---- top of tap: everything read during the previous tap has landed ---------------------------------------
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_waitcnt(0xC07F);                // lgkmcnt(0)
-      __builtin_amdgcn_sched_barrier(0);
+      // Fragment reads are UNCONDITIONAL (a dead tile reads its slot anyway; only its MFMAs are skipped), so the number of
+      // reads in flight is static and the compiler places an exact s_waitcnt lgkmcnt(N) in front of each tile's MFMAs
+      // instead of one full drain per tap.
       if (R > 1 && last_u && pair_end) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's reads of the slot are done
         // shared slots (k = 3): confirm the next pair's weights before this tap prefetches their first fragments, and
         // free the current slot for the fill the next row starts (conv8.hip)
         wait_vm0();
@@ -205,22 +205,12 @@ __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
       }
       uint4(&bc)[2][2] = b[u & 1];
       uint4(&bn)[2][2] = b[(u + 1) & 1];
-      if (m_rd) load_b(bn, bsrc);                        // there is a next tap in this chunk
+      load_b(bn, bsrc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (!last_u) {
-          if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) {
-            tile_mma(j, bc);
-            a[j][0] = lds128n(nb0 + j * kTileN);
-            a[j][1] = lds128n(nb1 + j * kTileN);
-          }
-        } else {
-          if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) tile_mma(j, bc);
-          if (__builtin_expect((m_rd & (1u << j)) != 0, 1)) {
-            a[j][0] = lds128n(nb0 + j * kTileN);
-            a[j][1] = lds128n(nb1 + j * kTileN);
-          }
-        }
+        if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) tile_mma(j, bc);
+        a[j][0] = lds128n(nb0 + j * kTileN);
+        a[j][1] = lds128n(nb1 + j * kTileN);
       }
     }
     if (R == 1) {
