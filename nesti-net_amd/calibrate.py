@@ -48,6 +48,9 @@ GATE_MARGIN_SIGMAS = 7.0     # tau = this many standard deviations of the f16 ga
 GATE_MARGIN_OVER_MAX = 1.25  # ... and at least this x the largest such error seen on the calibration sample
 
 
+GATE_MARGIN_MIN_QUERIES = 256   # fewer calibration queries than this: no filtering (every query is decided by the f16x3 gate)
+
+
 def calibrate_gate_margin(net, points, n_eff, sigmas=GATE_MARGIN_SIGMAS, over_max=GATE_MARGIN_OVER_MAX, floor=1e-3):
     """Set the gate margin tau of an 'f16x3c' :class:`NestiNet` (``nesti_model_set_gate_margin``) from a sample of queries
     (``points`` [B,S*P,3] / ``n_eff`` [B,S] device tensors).
@@ -59,7 +62,12 @@ def calibrate_gate_margin(net, points, n_eff, sigmas=GATE_MARGIN_SIGMAS, over_ma
     ``sigmas`` x sigma) has its arg-max flipped with probability < (E - 1) x P(|N(0, 1)| > 7) = 1.5e-11: one in 10^5
     clouds of 100k points.  Every later forward call re-measures sigma and the largest error on the queries it decides
     twice (:meth:`NestiNet.cascade_stats`; those are an unbiased sample because the error does not depend on the margin),
-    so a margin that has become too small for the data shows up as ``max_margin_err`` approaching tau.  Returns tau."""
+    so a margin that has become too small for the data shows up as ``max_margin_err`` approaching tau.  Returns tau.
+    A sample of fewer than ``GATE_MARGIN_MIN_QUERIES`` queries cannot carry a 7-sigma statement: the margin is then left at
+    infinity, which makes the mode plain f16x3 (always safe, no filter gain)."""
+    if int(points.shape[0]) < GATE_MARGIN_MIN_QUERIES:
+        net.set_gate_margin(1e30)
+        return float("inf")
     net.cascade_stats(reset=True)
     net.set_gate_margin(1e30)
     net.gate(net.mups(points, n_eff))

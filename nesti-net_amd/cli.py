@@ -115,6 +115,9 @@ def main(argv=None):
         st = est.net.cascade_stats()
         printout("two-stage gate: %d of %d queries decided by the f16x3 gate, f16 gate error on a logit difference <= %.4g "
                  "(tau %.4g)" % (st["rechecked"], st["queries"], st["max_margin_err"], st["tau"]))
+        if st["max_margin_err"] > 0.8 * st["tau"]:
+            printout("WARNING: the f16 gate's measured error came within 20 %% of the margin on this data; an arg-max of a query "
+                     "that was not rechecked may differ from the f16x3 result -- re-run with --dtype f16x3 to rule that out")
     flog.close()
     return 0
 

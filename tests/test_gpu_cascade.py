@@ -77,6 +77,8 @@ def test_calibrated_margin_reproduces_the_f16x3_decisions(case, gpu_device):
     from nesti_net_amd.model import NestiNet
     cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
     net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
+    assert calibrate_gate_margin(net, points[:100], n_eff[:100]) == float("inf")   # too few queries to calibrate on: no filtering
+    assert net.cascade_stats()["tau"] > 1e29
     tau = calibrate_gate_margin(net, points[:1024], n_eff[:1024])
     assert 0 < tau < 2.0
     normals, expert, probs = net(points, n_eff)
