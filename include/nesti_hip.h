@@ -14,8 +14,9 @@
  *     unless stated;
  *   - return value 0 = ok, non-zero = error; nesti_last_error() returns a
  *     thread-local message for the last failing call on this thread;
- *   - model handles are immutable after creation: concurrent forward calls on
- *     different streams are safe provided they use different workspaces.
+ *   - model handles are immutable after creation (except the NESTI_F16X3C gate margin, which must not be changed while
+ *     forward calls are in flight, and its device-side counters, which forward calls update atomically): concurrent
+ *     forward calls on different streams are safe provided they use different workspaces.
  */
 #ifndef NESTI_HIP_H
 #define NESTI_HIP_H
