@@ -176,6 +176,12 @@ __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
       mma<DT>(acc[j][1], a[j][0], bc[1][0]);
       mma<DT>(acc[j][0], a[j][1], bc[0][1]);
       mma<DT>(acc[j][1], a[j][1], bc[1][1]);
+#ifdef CONV8N_DOUBLE_MMA   // timing-only experiment (wrong results): twice the MFMAs per (chunk, tap) step on the same fragment reads
+      mma<DT>(acc[j][0], a[j][0], bc[0][1]);
+      mma<DT>(acc[j][1], a[j][0], bc[1][1]);
+      mma<DT>(acc[j][0], a[j][1], bc[0][0]);
+      mma<DT>(acc[j][1], a[j][1], bc[1][0]);
+#endif
     }
   };
   // one (dz, dy) row of K taps
