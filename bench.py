@@ -172,7 +172,8 @@ def mups_leg(points, steps, warmup, cfg, dev):
                      "kernel_ms_per_step": {"mups": ms["input"]["mups"] / steps, "patches": ms["input"]["patches"] / steps}}}
 
 
-def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, use_pg, timing, want_shard0=True, strong=False):
+def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, use_pg, timing, want_shard0=True, strong=False,
+              streams=1):
     """W warm-up steps, then exactly ``steps`` timed steps between barrier + synchronize pairs; max over ranks.
     ``strong``: a step is ONE cloud (clouds_np[0]) whose rows are sharded over the ranks (dist.estimate_sharded).
     Returns the elapsed seconds, the kernel-time table (rank 0), the last cloud's gathered results, this rank's
@@ -181,16 +182,23 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     if strong:
         clouds_np = clouds_np[:1]
     rank_rows = sum(ndist.max_shard(len(p), world) for p, _ in clouds_np)      # rows of all clouds on one rank
-    est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=min(args.batch, rank_rows, MAX_BATCH.get(dtype, 1 << 30)),
-                          use_graph=args.graph, n_streams=args.streams)
+    batch = min(args.batch, rank_rows, MAX_BATCH.get(dtype, 1 << 30))
+    if args.graph:
+        streams = 1
+    if streams > 1:          # `streams` library batches in flight, together no more rows than one single-stream batch would hold
+        batch = max(256, min(batch, (((rank_rows + streams - 1) // streams) + 255) // 256 * 256, (batch // streams + 255) // 256 * 256))
+    est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=batch, use_graph=args.graph, n_streams=streams)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
     res = {}
     if dtype == "f16x3c":
         # the gate margin: measured on a 1024-query sample of cloud 0 (every rank derives the same value), calibrate.py
         from nesti_net_amd.calibrate import GATE_MARGIN_SIGMAS, calibrate_gate_margin
         sp, sn = clouds[0].build(0, min(1024, clouds[0].patch_count))
-        res["gate_margin"] = {"tau": calibrate_gate_margin(est.net, sp, sn), "sigmas": GATE_MARGIN_SIGMAS,
-                              "calibration_queries": int(sp.shape[0])}
+        tau = calibrate_gate_margin(est.net, sp, sn)
+        # sigma comes out of floating-point atomics: the ranks' values may differ in their last bits, all adopt the largest
+        tau, spread = ndist.agree_on_gate_margin(est.net, tau, dev)
+        res["gate_margin"] = {"tau": tau, "sigmas": GATE_MARGIN_SIGMAS, "calibration_queries": int(sp.shape[0]),
+                              "tau_max_minus_min_over_ranks": spread}
         del sp, sn
 
     def step():
@@ -229,7 +237,8 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
         lib.nesti_profile_enable(0)
     if dtype == "f16x3c":
         res["cascade"] = est.net.cascade_stats()                      # rank 0's counters over the timed steps
-    res.update({"elapsed": elapsed, "batch": est.batch, "steps": steps, "out": [t.cpu().numpy() for t in out]})
+    res.update({"elapsed": elapsed, "batch": est.batch, "streams": est.n_streams, "steps": steps,
+                "out": [t.cpu().numpy() for t in out]})
     if rank == 0:
         if want_shard0:
             lo, hi = ndist.shard_range(clouds[0].patch_count, 0, world)
@@ -311,7 +320,7 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
     # scripts/summarize_pmc.py).  Counters cannot be read from inside the process, so the figure is quoted from
     # the profile only when dtype, batch and routing match; otherwise null.
     traffic, src = None, None
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         pmc_file = os.path.join(REPO, "profiles", name)
         if traffic is None and os.path.exists(pmc_file):
             pj = json.load(open(pmc_file))
@@ -319,7 +328,7 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
                 traffic = pj["kernels"]["conv"]["hbm_bytes_per_query"] * rank0_pts / max(1, conv_n)
                 src = "profiles/%s (separate --pmc passes of this bench configuration)" % name
     return {
-        "bound": "mfma", "kernel": "conv8_kernel + conv_igemm_kernel (all conv3d/fc layers)", "achieved": tot[1], "peak": peak,
+        "bound": "mfma", "kernel": "conv8n_kernel + conv_igemm_kernel (all conv3d/fc layers)", "achieved": tot[1], "peak": peak,
         "unit": "TFLOP/s", "frac": tot[1] / peak, "traffic": traffic, "traffic_source": src,
         "algorithmic_gflop_per_point": 2 * (per_pt(-1, 1, "gate") + per_pt(-1, 1, "experts")) / 1e9, "nominal_tflops": tot[0],
         "mfma_issued_tflops": issued_all / conv_s / 1e12, "frac_mfma_issued": issued_all / conv_s / 1e12 / peak,
@@ -355,9 +364,11 @@ def main():
     ap.add_argument("--stream-clouds", type=int, default=0,
                     help="BASELINE config 4: this many clouds of varying size/density in flight per step instead of one "
                          "--points cloud per rank (not the headline workload)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="alternate consecutive batches between this many HIP streams (2 is ~3%% faster, but kernels of the two "
-                         "streams overlap, so per-launch durations no longer describe one kernel)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="library batches in flight on this many HIP streams during the headline run (default 2, as the product "
+                         "command line runs: nesti-net_amd/cli.py).  Kernels of two streams overlap, so per-launch durations no "
+                         "longer describe one kernel: the roofline object comes from a separate single-stream pass of the same "
+                         "workload (printed as 'single_stream')")
     ap.add_argument("--mups-only", action="store_true",
                     help="BASELINE config 1: time only patch extraction + the MuPS kernel (f32 [B,8,8,8,60] output); prints its "
                          "own JSON line with the VALU / HBM roofline fractions (not the headline workload)")
@@ -408,12 +419,16 @@ def main():
         del cp, sp, sn
     timing = (rank == 0) and not args.no_kernel_timing
     headline = not args.stream_clouds
-    main_run = timed_run(args, cfg, W, clouds_np, args.dtype, args.steps, args.warmup, dev, world, rank, use_pg, timing,
-                         want_shard0=not args.no_parity and args.dtype != "f32")
+    main_run = timed_run(args, cfg, W, clouds_np, args.dtype, args.steps, args.warmup, dev, world, rank, use_pg,
+                         timing and args.streams == 1, want_shard0=not args.no_parity and args.dtype != "f32", streams=args.streams)
+    # per-kernel times need launches that do not overlap: a short single-stream pass of the same workload carries the roofline
+    roof_run = main_run
+    if timing and main_run["streams"] > 1:
+        roof_run = timed_run(args, cfg, W, clouds_np, args.dtype, 2, 1, dev, world, rank, use_pg, True, want_shard0=False)
     strong = None
     if headline and (world > 1 or args.strong):
         strong = timed_run(args, cfg, W, clouds_np, args.dtype, max(2, min(args.steps, 5)), 1, dev, world, rank, use_pg, False,
-                           want_shard0=False, strong=True)
+                           want_shard0=False, strong=True, streams=args.streams)
     legs = {}
     if headline and not args.no_secondary and world == 1:
         # the other modes on the same workload, a few steps each, each with its own parity object against the fp32 mode
@@ -436,20 +451,33 @@ def main():
                                    "%d cloud(s) x %s points, rows sharded over %d rank(s) + all-gather"
                                    % (len(clouds_np), ("%d..%d" % (min(len(p) for p, _ in clouds_np), max(len(p) for p, _ in clouds_np)))
                                       if args.stream_clouds else str(args.points), world),
-                       "points_per_cloud": args.points, "batch": main_run["batch"], "weights": "synthetic seed %d" % weights.WEIGHT_SEED,
+                       "points_per_cloud": args.points, "batch": main_run["batch"], "streams": main_run["streams"],
+                       "weights": "synthetic seed %d" % weights.WEIGHT_SEED,
                        "routing_histogram": hist.tolist(), "parallelism": "dp%d (query rows)" % world},
         }
         if "cascade" in main_run:
             c = main_run["cascade"]
             res["gate_cascade"] = {**main_run["gate_margin"], **c, "rechecked_frac": c["rechecked"] / max(1, c["queries"]),
                                    "tau_over_max_margin_err": c["tau"] / c["max_margin_err"] if c["max_margin_err"] else None,
+                                   "tau_eff_over_max_margin_err": c["tau_eff"] / c["max_margin_err"] if c["max_margin_err"] else None,
+                                   "rounds_widened": c["widen_events"],
                                    "note": "f16 filter pass over every query, f16x3 gate over those whose f16 top-2 logit margin "
-                                           "< tau; max_margin_err = the f16 pass's largest error on a logit difference among the "
-                                           "rechecked queries of the timed steps (a flip of an unrechecked query needs >= tau)"}
+                                           "< tau_eff = max(tau, 1.5 x max_margin_err so far); max_margin_err = the f16 pass's largest "
+                                           "error on a logit difference among the rechecked queries of the timed steps; when a call "
+                                           "measures an error above tau_eff / 1.5 it re-decides the band up to 1.5 x that error in a "
+                                           "widening round (rounds_widened calls did, 'widened' queries): an unrechecked query always "
+                                           "keeps a margin >= 1.5 x the largest error measured"}
         frac = hist / max(1, hist.sum())
         cal = not args.uncalibrated_gate
         if timing:
-            res["roofline"] = roofline(main_run, args.dtype, cfg, clouds_np, world, frac, cal)
+            res["roofline"] = roofline(roof_run, args.dtype, cfg, clouds_np, world, frac, cal)
+            if roof_run is not main_run:
+                res["single_stream"] = {"value": sum(len(p) for p, _ in clouds_np) * roof_run["steps"] / roof_run["elapsed"],
+                                        "unit": "normals/sec", "steps": roof_run["steps"], "warmup": 1, "batch": roof_run["batch"],
+                                        "ms_per_step": 1e3 * roof_run["elapsed"] / roof_run["steps"],
+                                        "note": "the same workload on ONE stream with per-launch hipEvents: the pass 'roofline' is "
+                                                "computed from (with two streams in flight kernels overlap and a launch's duration "
+                                                "no longer describes one kernel)"}
         if strong is not None:
             res["strong"] = {"scaling": "strong", "value": len(clouds_np[0][0]) * strong["steps"] / strong["elapsed"],
                              "unit": "normals/sec", "steps": strong["steps"], "warmup": 1,

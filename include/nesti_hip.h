@@ -44,8 +44,9 @@ enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16
  * first runs in plain f16 as a FILTER: a query whose f16 top-2 logit margin is at least the gate margin tau keeps the f16
  * arg-max (a flip would need an f16 logit error of tau), every other query is decided again by the f16x3 gating net.
  * expert_out / normals_out are then those of NESTI_F16X3 as long as the f16 gate's error on a logit difference stays below
- * tau, which every call re-measures on the queries it decides twice (nesti_model_cascade_stats); probs_out carries the
- * f16 gate's probabilities for the queries that were not re-decided. */
+ * the margin, which every call re-measures on the queries it decides twice and widens by itself when the measured error
+ * comes within a factor NESTI_GATE_WIDEN of it (nesti_model_cascade_stats); probs_out carries the f16 gate's probabilities
+ * (within ~0.02 of NESTI_F16X3's) for the queries that were not re-decided. */
 
 /* which graph nesti_model_create builds */
 enum {
@@ -154,22 +155,33 @@ void nesti_model_destroy(nesti_model_t* m);
 
 /* ---- NESTI_F16X3C: the gate margin and the running statistics of the two-stage gate ---------------------------------
  * tau is in units of the gating net's last-layer outputs (the values softmax sees, models/experts_n_est.py:174-177).
+ * The margin protects itself: a forward call filters with
+ *     tau_eff = max(tau, NESTI_GATE_WIDEN x max_margin_err measured since the last reset)
+ * and, after its own recheck rounds, re-decides the rows whose f16 margin lies between that threshold and NESTI_GATE_WIDEN x
+ * the (possibly larger) error it has just measured -- a second, normally empty round on the device, no host
+ * synchronisation.  A row keeps the f16 arg-max only while its margin is at least NESTI_GATE_WIDEN x the largest error the
+ * f16 gate has shown on any row decided twice.
  * nesti_model_cascade_stats synchronises `stream`, copies the counters accumulated by every forward call since the last
  * reset and optionally resets them:
  *   queries        rows that went through the gate,
- *   rechecked      rows whose f16 top-2 margin was below tau (decided by the f16x3 gate),
+ *   rechecked      rows decided by the f16x3 gate (f16 top-2 margin below tau_eff, or caught by a widening round),
  *   changed        rechecked rows whose arg-max differs between the two gates,
  *   max_margin_err largest |(l_a - l_k)_f16 - (l_a - l_k)_f16x3| over the rechecked rows and all experts k, a = the f16
- *                  arg-max: the f16 gate's error on exactly the quantity tau guards.  It must stay well below tau.
+ *                  arg-max: the f16 gate's error on exactly the quantity tau guards,
  *   sum_sq_pair_err / pairs: the same errors squared and summed over all (rechecked row, k != a) pairs, and their count:
  *                  sqrt(sum / pairs) is the standard deviation sigma of the f16 pass's error on one logit difference (the
- *                  errors are rounding noise: zero-mean, independent of the margin); tau is chosen as a multiple of it. */
+ *                  errors are rounding noise: zero-mean, independent of the margin); tau is chosen as a multiple of it,
+ *   widened        rows re-decided by a widening round, widen_events: forward calls whose widening round was not empty,
+ *   tau_eff        the threshold the next forward call starts from. */
+#define NESTI_GATE_WIDEN 1.5f
 typedef struct {
   uint64_t queries, rechecked, changed;
   float max_margin_err;
   float tau;
   double sum_sq_pair_err;
   uint64_t pairs;
+  uint64_t widened, widen_events;
+  float tau_eff;
 } nesti_cascade_stats_t;
 int nesti_model_set_gate_margin(nesti_model_t* m, float tau);
 int nesti_model_cascade_stats(const nesti_model_t* m, nesti_cascade_stats_t* out, int reset, void* stream);

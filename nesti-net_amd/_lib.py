@@ -30,7 +30,11 @@ class CCascadeStats(ctypes.Structure):
     """Mirror of ``nesti_cascade_stats_t``."""
     _fields_ = [("queries", ctypes.c_uint64), ("rechecked", ctypes.c_uint64), ("changed", ctypes.c_uint64),
                 ("max_margin_err", ctypes.c_float), ("tau", ctypes.c_float),
-                ("sum_sq_pair_err", ctypes.c_double), ("pairs", ctypes.c_uint64)]
+                ("sum_sq_pair_err", ctypes.c_double), ("pairs", ctypes.c_uint64),
+                ("widened", ctypes.c_uint64), ("widen_events", ctypes.c_uint64), ("tau_eff", ctypes.c_float)]
+
+
+GATE_WIDEN = 1.5      # NESTI_GATE_WIDEN (include/nesti_hip.h)
 
 
 class NestiError(RuntimeError):

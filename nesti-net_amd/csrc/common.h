@@ -27,7 +27,7 @@ void set_error(const std::string& msg);
   } while (0)
 
 static inline size_t dtype_size(int dt) { return dt == NESTI_F32 ? 4 : 2; }
-// NESTI_BF16X3: the kernels are the bf16 ones with the pair K loop (conv.hip / conv8.hip: X3); an activation row holds, per
+// NESTI_BF16X3: the kernels are the bf16 ones with the pair K loop (conv.hip / conv8n.hip: X3); an activation row holds, per
 // group of 64 channels, the two 64-element planes [hi | lo] (128 elements), a packed weight row [W_hi | W_lo] per K chunk,
 // and one set of fragment reads feeds hi*W_hi + lo*W_hi + hi*W_lo.  Writers emit the planes (split_col / split_pack2 below).
 // NESTI_F16X3: the same with f16 pairs and the f16 kernels.

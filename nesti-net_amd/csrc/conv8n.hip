@@ -1,19 +1,56 @@
-// conv8_kernel with A-fragment reuse: the same k^3-tap conv3d layers on the 8^3 volume (k = 3, 5; conv8.hip has the full
-// story), but a wave owns FOUR x-line tiles x TWO 32-column tiles instead of eight x one, so that every A fragment read from
-// LDS feeds two MFMAs (plain modes) or three + three (pair modes): 0.75 / 0.5 KB of LDS reads per MFMA instead of 1.125 /
-// 0.75 -- worth 2-5 % same-box; these kernels sit within ~10 % of the matrix pipe's own rate on such data.
+// k^3-tap conv3d on the 8^3 volume (k = 3, 5): the dominant layers of the network (the 5^3 taps at 8^3 are ~2/3 of all
+// multiply-accumulates of a top-1 forward pass).
+//
+// Same arithmetic as conv_igemm_kernel (conv.hip): tf.nn.conv3d 'SAME' + bias_add + inference batch-norm (folded on the host)
+// + ReLU (utils/tf_util.py:298-311, 491-494), optionally followed by the block's 2^3 / 2 max-pool (utils/tf_util.py:424-428,
+// e.g. models/experts_n_est.py:198) fused into the epilogue.
+//
+// Why another kernel.  conv_igemm_kernel's time follows the number of MFMAs it issues and the weight bytes it streams
+// (profiles/r01_mfma_ubench.txt).  With one point per workgroup a 32-row MFMA tile spans several y or z values, so a padding
+// tap can only skip it when ALL of them leave the volume (issued / nominal 0.81 for 5^3, against 0.61 useful), and every
+// workgroup re-streams every tap's weight tile for its one point.  Here
+//   * an MFMA tile is the x-line (y, z) of FOUR points (32 rows = 4 points x 8 x): a tap (dz, dy, dx) skips the tile exactly
+//     when y + dy or z + dz leaves the volume, at single-voxel granularity on both axes (issued / nominal 0.72 for 5^3, 0.84
+//     for 3^3), and the skip is a scalar test -- all 32 rows of a tile share (y, z);
+//   * the K chunk is 64 bytes per row (32 x 16-bit or 16 x f32 channels), so the 4 points' chunk stays resident in LDS for
+//     all k^3 taps and a tap's weight tile serves 4 points instead of one: a quarter of the weight stream per output;
+//   * the only per-lane padding test left is x + dx: an out-of-range lane reads an LDS address beyond the allocation, which
+//     returns zeros on gfx950 (scripts/lds_oob_probe.hip; checked at model creation, conv8_selftest), so no zero rows are kept;
+//   * a wave owns FOUR x-line tiles x TWO 32-column tiles, so that every A fragment read from LDS feeds two MFMAs (plain
+//     modes) or three + three (pair modes): 0.75 / 0.5 KB of LDS reads per MFMA (round 3: 1.125 / 0.75 with eight tiles x one
+//     column tile per wave, 2-5 % slower same-box; these kernels sit within ~10 % of the matrix pipe's own rate on such data,
+//     DESIGN.md 4.3).
 //
 // Workgroup = 4 points x ONE z half of the output volume (z in [4h, 4h + 4)) x 64 output channels.  It stages the
 // NZ = 4 + k/2 source planes that half can reach (6 of 8 for k = 5: 96 KiB instead of 128) and 4 KiB of weights per tap.
-// Tile (y, z) of the half lives with wave (y + z) & 7, as in conv8_kernel, so the four tiles a wave reads for tap
-// (dz, dy) are consecutive slots of wave (w + dy + dz) & 7's run; source plane z' sits at slot NZ * ((y' + z') & 7) + z' - zlo.
-// Waves w and w + 4 (one SIMD) together hold all eight y lines of every z plane of the half: whatever a tap kills, the four
-// matrix pipes lose the same number of tiles.
+// Tile (y, z) of the half lives with wave (y + z) & 7 -- every wave owns one tile of every z plane and one of every y plane
+// (a Latin square), so whatever planes a tap kills, every wave, hence every SIMD's matrix pipe, loses the same number of
+// tiles -- and the four tiles a wave reads for tap (dz, dy) are consecutive slots of wave (w + dy + dz) & 7's run; source
+// plane z' sits at slot NZ * ((y' + z') & 7) + z' - zlo.  A fragment address is one per-lane base (x + dx shift, swizzle)
+// plus a wave-uniform base plus a compile-time j * 2048.  Waves w and w + 4 (one SIMD) together hold all eight y lines of
+// every z plane of the half.
+//
+// Pipeline.  The weight tiles of one (dz, dy) row of taps stream L2 -> LDS by LDS-DMA two rows ahead into 3 slots, one barrier
+// per row (k = 5); pairs of rows one pair ahead into 2 slots, one barrier per pair (k = 3).  Within a wave the A fragments of
+// tap t + 1 are read into the registers tile j's MFMAs of tap t have just consumed (a full tap of lookahead).
 //
 // LDS: [0, 64 KiB) weight slots (3 x 20 KiB rows for k = 5, 2 x 24 KiB row pairs for k = 3), [64 KiB, 64 + 16 NZ KiB) the
-// input chunk.  Everything else -- swizzles, LDS-DMA staging, out-of-range reads for the x padding, the one-tap fragment
-// lookahead, the fused 2^3 max-pool epilogue -- is conv8_kernel's.
+// input chunk; rows are 64 B with the 16-B slot XOR-swizzled by the point index (input) / (row >> 2) & 3 (weights), applied on
+// the DMA source address, which makes every ds_read_b128 lane group conflict-free.  The epilogue reuses the LDS as an fp32
+// staging tile.
+//
+// X3 (pair modes, model.hip: PackedLayer::x3n): the K chunk is 16 channels -- an LDS row holds [hi k0..15 | lo k0..15] of the
+// activation pair (staged from the two planes of the [hi 64 | lo 64] row groups) and a weight row [W_hi k0..15 | W_lo k0..15]
+// -- and a tap multiplies hi * W_hi + lo * W_hi + hi * W_lo from ONE set of fragment reads.
+//
+// What did NOT pay (profiles/r02_conv8_experiments.txt): seven re-schedulings of this loop -- waves out of
+// phase, counted vmcnt, hand-counted lgkmcnt with inline-asm reads, adjacent MFMA pairs, K-step-major order, weights straight
+// from L2 into registers without a row barrier, barrier-free rows through LDS counters -- all within +-3 % or slower.  The
+// kernel runs against the chip's power / clock limit: its time follows the MFMAs issued and the operand bits they toggle
+// (zero data: +9 %), which is what the tile layout above reduces.
 #include <string.h>
+
+#include <mutex>
 
 #include <type_traits>
 
@@ -47,7 +84,7 @@ __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
   constexpr int LO = (K - 1) / 2;
   constexpr int NG = K * K;                  // (dz, dy) rows of taps per chunk
   constexpr int NZ = 4 + LO;                 // staged source planes
-  constexpr int R = (K == 3) ? 2 : 1;        // rows of taps per weight slot (conv8.hip)
+  constexpr int R = (K == 3) ? 2 : 1;        // rows of taps per weight slot
   constexpr int NS = (K == 3) ? 2 : 3;
   constexpr int AHEAD = NS - 1;
   constexpr int kSlot = R * K * kBTileN;
@@ -201,7 +238,7 @@ __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
       if (R > 1 && last_u && pair_end) {
         __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's reads of the slot are done
         // shared slots (k = 3): confirm the next pair's weights before this tap prefetches their first fragments, and
-        // free the current slot for the fill the next row starts (conv8.hip)
+        // free the current slot for the fill the next row starts
         wait_vm0();
         __builtin_amdgcn_s_barrier();
       }
@@ -384,9 +421,11 @@ __global__ void lds_oob_probe_kernel(unsigned* out, unsigned lds) {
 int conv8_selftest() {
   constexpr int kMaxDevices = 64;
   static int state[kMaxDevices] = {};          // 0: not run, 1: passed, 2: failed
+  static std::mutex mu;                        // models may be created from several host threads
+  std::lock_guard<std::mutex> lk(mu);
   int dev = 0;
   NESTI_CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= kMaxDevices) return 0;
+  if (dev < 0 || dev >= kMaxDevices) NESTI_FAIL("conv8_selftest: device index out of range");
   if (state[dev] == 1) return 0;
   if (state[dev] == 0) {
     hipDeviceProp_t prop;
@@ -409,7 +448,7 @@ int conv8_selftest() {
     }
   }
   if (state[dev] == 2)
-    NESTI_FAIL("this device is not a gfx950 whose out-of-range LDS reads return zero: the 8^3 tap kernels (conv8.hip, conv8n.hip) "
+    NESTI_FAIL("this device is not a gfx950 whose out-of-range LDS reads return zero: the 8^3 tap kernels (conv8n.hip) "
                "take their x padding from such reads and would compute wrong convolutions here");
   return 0;
 }

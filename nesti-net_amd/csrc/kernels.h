@@ -24,6 +24,8 @@ struct ConvParams {
   const int32_t* point_index;   // optional gather of INPUT points (routing); NULL -> identity
   int npoints;         // capacity (grid is sized for this)
   int in_cstride, in_coff;
+  int in_chunk_bytes;  // plain (non-pair) K loop of conv_igemm_kernel: byte distance between consecutive 128-byte K chunks of an
+                       // input row -- 128, or 256 when a plain-f16 layer reads the hi planes of a pair-layout tensor (model.hip)
   int out_cstride, out_coff;
   int n_chunks, n_taps;
   int log2S;           // S in {1,2,4,8}: the index space rows are laid out in
@@ -50,7 +52,7 @@ struct ConvParams {
   // NESTI_BF16X3 / NESTI_F16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (two planes per
   // 64-channel group); out_coff / out_coff2 stay logical and every 16-bit store goes through split_col + two planes.
   int split;
-  int x3native;        // pair modes: the kernels' pair K loop (conv.hip / conv8.hip: X3) -- K chunks [hi | lo] x [W_hi | W_lo], three MFMAs
+  int x3native;        // pair modes: the kernels' pair K loop (conv.hip / conv8n.hip: X3) -- K chunks [hi | lo] x [W_hi | W_lo], three MFMAs
                        // per fragment set; the packed weights follow (model.hip: PackedLayer::x3n)
   float acc_scale;     // the accumulators are multiplied by this before the bias (1, or 2^-s when the layer's packed weights
                        // carry a 2^s scale: NESTI_F16X3 keeps the weight pairs in f16's normal range that way)
@@ -89,11 +91,20 @@ int launch_maxpool3s2(const PoolParams& p, int dtype, hipStream_t stream);
 int launch_gate_finish(const float* logits, int lstride, int B, int E, float* probs,
                        int32_t* expert, int32_t* counts /*[E] or NULL*/,
                        int32_t* lists /*[E][B] or NULL*/, hipStream_t stream);
-// NESTI_F16X3C, stage 1 / stage 2 of the two-stage gate (pool.hip): keep [B, NESTI_MAX_EXPERTS] f32, flag_list [B],
-// round_counts [n_rounds] = flagged rows of each `cap`-sized recheck round, cstat = the model's device counters
-int launch_gate_flag(const float* logits, int lstride, int B, int E, float tau, float* probs, int32_t* expert, float* keep,
-                     int32_t* flag_count, int32_t* flag_list, int cap, int n_rounds, int32_t* round_counts,
-                     unsigned long long* cstat, hipStream_t stream);
+// NESTI_F16X3C, the two-stage gate (pool.hip): keep [B, NESTI_MAX_EXPERTS] f32 (the f16 pass's logits), flag_list [B],
+// cstat = the model's device counters, fcounts = a 512-byte block of the call's workspace laid out as int32 words:
+//   [0] rows flagged by the filter pass, [kRoundCountsOff + r] of them in recheck round r (cap rows per round),
+//   [kTauEffOff] the call's threshold tau_eff as a float, [kWidenCountOff] rows flagged by the widening round,
+//   [kWidenRoundsOff + r] of them in widening round r
+constexpr int kMaxCascadeRounds = 24;
+constexpr int kRoundCountsOff = 8, kTauEffOff = 40, kWidenCountOff = 48, kWidenRoundsOff = 56;
+static_assert(kRoundCountsOff + kMaxCascadeRounds <= kTauEffOff && kWidenRoundsOff + kMaxCascadeRounds <= 128, "fcounts layout");
+int launch_gate_flag(const float* logits, int lstride, int B, int E, float tau, float widen, float* probs, int32_t* expert,
+                     float* keep, int32_t* fcounts, int32_t* flag_list, int cap, int n_rounds, unsigned long long* cstat,
+                     hipStream_t stream);
+// after the recheck rounds: the flag list (storage reused) of the rows in [tau_eff, widen * max_margin_err) and its round counts
+int launch_gate_widen(const float* keep, int B, int E, float widen, int32_t* fcounts, int32_t* flag_list, int cap, int n_rounds,
+                      unsigned long long* cstat, hipStream_t stream);
 int launch_gate_recheck(const float* logits, int lstride, const int32_t* flag_list, const int32_t* count_ptr, int cap, int E,
                         const float* keep, float* probs, int32_t* expert, unsigned long long* cstat, hipStream_t stream);
 // out[i * n_rounds + r] = clamp(counts[i] - r * cap, 0, cap): the rows of list i that round r of a `cap`-row tower covers

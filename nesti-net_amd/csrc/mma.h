@@ -1,4 +1,4 @@
-// MFMA / LDS-DMA primitives shared by the conv kernels (conv.hip, conv8.hip).  gfx950 only.
+// MFMA / LDS-DMA primitives shared by the conv kernels (conv.hip, conv8n.hip).  gfx950 only.
 #pragma once
 #include "kernels.h"
 

@@ -161,12 +161,6 @@ struct Graph {
   std::vector<Tower> experts;
 };
 
-// A/B switch for same-box comparisons (NESTI_FUSE_CONV4_MAXPOOL=0: the standalone max-pool kernel for conv4's columns)
-bool fuse_conv4_maxpool() {
-  static const int v = [] { const char* e = getenv("NESTI_FUSE_CONV4_MAXPOOL"); return e ? atoi(e) : 1; }();
-  return v != 0;
-}
-
 struct Builder {
   Graph& g;
   int s_real = 0;            // stamped on the layers built while it is set (conv_net_3g)
@@ -213,7 +207,7 @@ struct Builder {
          scope + "_conv4", Fp + Hp + Hp, k0);
     // conv4 behind a max-pool: when its avg-pool runs in the epilogue (k0 > 1) the 2^3 max is taken there as well and
     // its full-resolution columns are never written; with k0 == 1 (plain columns) the small standalone kernel pools them
-    const bool fuse4 = then_maxpool && k0 > 1 && !s_real && fuse_conv4_maxpool();
+    const bool fuse4 = then_maxpool && k0 > 1 && !s_real;
     if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 2; T.ops.back().mp_mode2 = fuse4 ? 1 : 0; }
     conv(T, scope + "_conv2", k0, log2S, ob, 0, c1, H, ob, Fp);
     if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 1; }
@@ -428,9 +422,9 @@ struct PackedLayer {
   void* wpk = nullptr;
   float* bias = nullptr;
   int TN = 64, n_tiles = 0, split_tile = 0, n_chunks = 0, n_taps = 0;
-  int kind = 0;              // 0: conv_igemm_kernel (conv.hip), 1: conv8_kernel (conv8.hip: 4 points per workgroup),
-                             // 2: conv8n_kernel (conv8n.hip: 4 points x a z half x 64 columns per workgroup)
-  bool x3n = false;          // pair modes on conv8_kernel: 16-channel K chunks [hi | lo] / [W_hi | W_lo], three MFMAs per fragment set
+  int kind = 0;              // 0: conv_igemm_kernel (conv.hip), 2: conv8n_kernel (conv8n.hip: 4 points x a z half x 64 columns
+                             // per workgroup)
+  bool x3n = false;          // pair modes: K chunks [hi | lo] / [W_hi | W_lo], three MFMAs per fragment set
   float acc_scale = 1.0f;    // 2^-s when the packed weights carry a 2^s scale (NESTI_F16X3)
   int8_t tap[kMaxTaps][4];
 };
@@ -522,19 +516,19 @@ int fold_layer(const LayerDesc& d, const std::string& scope, const TensorTable& 
   return 0;
 }
 
-// Which layers run on conv8_kernel: the k^3 taps on the 8^3 volume.  NESTI_CONV8 = 0: none (everything on
-// conv_igemm_kernel), 1: the 5^3 layers, 2 (default): the 3^3 layers too.
+// Which layers run on conv8n_kernel (conv8n.hip): the k^3 taps (k = 3, 5) on the 8^3 volume; everything else is
+// conv_igemm_kernel's (conv.hip)
 bool use_conv8(const LayerDesc& d) {
-  static const int mode = [] { const char* e = getenv("NESTI_CONV8"); return e ? atoi(e) : 2; }();
   if (d.is_fc || d.log2S != 3 || d.s_real || !d.scope2.empty()) return false;
-  return (d.k == 5 && mode >= 1) || (d.k == 3 && mode >= 2);
+  return d.k == 5 || d.k == 3;
 }
 
-// Error attribution in the pair modes (scripts/exp_attribution.py): NESTI_X3_PLAIN = "regex,regex,..." -- a layer whose scope
-// matches drops the hi * W_lo product (its W_lo weights are packed as zeros: the layer then sees its weights rounded to 16 bits).
-// Round 3's full sweep (profiles/r03_attribution_sweep.txt) also switched off lo * W_hi per layer; that needed the three-plane
-// layout [hi | lo | hi] x [W_hi ; W_hi ; W_lo] of commit 6f246d7 and is not available in the two-plane layout.
-// Read at every model creation.
+// Error attribution in the pair modes (scripts/exp_attribution.py), ONLY in builds made with -DNESTI_ATTRIBUTION (the product
+// library has no such switch): NESTI_X3_PLAIN = "regex,regex,..." -- a layer whose scope matches drops the hi * W_lo product
+// (its W_lo weights are packed as zeros: the layer then sees its weights rounded to 16 bits).  Round 3's full sweep
+// (profiles/r03_attribution_sweep.txt) also switched off lo * W_hi per layer; that needed the three-plane layout
+// [hi | lo | hi] x [W_hi ; W_hi ; W_lo] of commit 6f246d7 and is not available in the two-plane layout.
+#ifdef NESTI_ATTRIBUTION
 int x3_drop_mask(const LayerDesc& d) {
   const char* e = getenv("NESTI_X3_PLAIN");
   if (!e || !*e) return 0;
@@ -548,12 +542,19 @@ int x3_drop_mask(const LayerDesc& d) {
     if (item.empty()) continue;
     try {
       const std::regex re(item);
-      if (std::regex_search(d.scope, re) || (!d.scope2.empty() && std::regex_search(d.scope2, re))) return 2;
+      if (std::regex_search(d.scope, re) || (!d.scope2.empty() && std::regex_search(d.scope2, re))) {
+        fprintf(stderr, "libnesti_hip (attribution build): layer %s packed WITHOUT its W_lo plane\n", d.scope.c_str());
+        return 2;
+      }
     } catch (const std::regex_error&) {
+      fprintf(stderr, "libnesti_hip (attribution build): bad regex '%s' in NESTI_X3_PLAIN\n", item.c_str());
     }
   }
   return 0;
 }
+#else
+inline int x3_drop_mask(const LayerDesc&) { return 0; }
+#endif
 
 int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer* pl) {
   const int n_parts = d.scope2.empty() ? 1 : 2;
@@ -577,18 +578,17 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
       }
   const size_t esz = dtype_size(dtype);
   // NESTI_BF16X3 / NESTI_F16X3 (common.h): a K chunk of a packed weight row is [W_hi | W_lo] for half as many channels as the
-  // plain chunk holds (the kernels' pair K loop multiplies hi*W_hi + lo*W_hi + hi*W_lo from it: conv.hip / conv8.hip, X3)
+  // plain chunk holds (the kernels' pair K loop multiplies hi*W_hi + lo*W_hi + hi*W_lo from it: conv.hip / conv8n.hip, X3)
   const int planes = act_planes(dtype);
   const int drop = planes > 1 ? x3_drop_mask(d) : 0;
-  // NESTI_CONV8N=0: the 8^3 tap layers on conv8_kernel (one 32-column tile per wave) instead of conv8n_kernel (same-box A/B)
-  static const bool conv8n = [] { const char* e = getenv("NESTI_CONV8N"); return e ? atoi(e) != 0 : true; }();
-  pl->kind = use_conv8(d) ? (conv8n && d.Cout_p % 64 == 0 ? 2 : 1) : 0;
+  pl->kind = use_conv8(d) ? 2 : 0;
+  if (pl->kind == 2 && d.Cout_p % 64) NESTI_FAIL("internal: conv8n_kernel needs 64-column tile pairs");
   pl->x3n = planes > 1;
   const int K_phys = d.Cin_p * planes;
   const int row_bytes = pl->kind >= 1 ? 64 : kRowBytes;   // bytes of one K chunk of one row
   const int KC = row_bytes / (int)esz;
   const int chunk_ch = KC / planes;                       // input channels per K chunk
-  pl->TN = pl->kind == 1 ? 32 : pl->kind == 2 ? 64 : (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
+  pl->TN = pl->kind == 2 ? 64 : (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
   pl->n_tiles = d.Cout_p / pl->TN;
   pl->split_tile = part_p / pl->TN * (n_parts == 2 ? 1 : n_parts);
   if (n_parts == 1) pl->split_tile = pl->n_tiles;
@@ -643,7 +643,7 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
             const int n = n_base + nl;
             if (n >= d.cout) break;
             const float v = wrow[n] * f.scale[n] * wmul;
-            // the kernels' LDS image: row nl, 16-B slot XOR-swizzled (conv8_kernel: 64-B rows, key (row >> 2) & 3)
+            // the kernels' LDS image: row nl, 16-B slot XOR-swizzled (conv8n_kernel: 64-B rows, key (row >> 2) & 3)
             unsigned char* dst = pl->kind >= 1
                 ? tile + (size_t)nl * 64 + ((slot ^ ((nl >> 2) & 3)) << 4) + within * esz
                 : tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
@@ -747,9 +747,7 @@ size_t tower_bytes(const Tower& T, int NB, int dtype) { return place_tower(T, NB
 // fall entirely on padding -- 5^3 taps at 8^3 (|d| = 2 clears a y/z pair) and every multi-tap layer at 4^3.  3^3 at
 // 8^3 only ever clears single planes, which no 32-row tile shape can balance over four SIMDs.
 int conv_remap(int k, int log2S, int n_taps) {
-  static const int force = [] { const char* e = getenv("NESTI_CONV_REMAP"); return e ? atoi(e) : -1; }();
   if (n_taps <= 1 || (log2S != 2 && log2S != 3)) return 0;
-  if (force >= 0) return force ? 1 : 0;
   return (log2S == 2 || k >= 4) ? 1 : 0;
 }
 
@@ -793,6 +791,9 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.split = planes > 1 ? 1 : 0;
       const int in_planes = ext_in ? x0_planes : planes;
       p.in_cstride = (op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C) * in_planes; p.in_coff = op.in_coff * in_planes;
+      // distance between consecutive K chunks of a PLAIN kernel's input row: 128 B, except in the NESTI_F16X3C filter pass,
+      // whose plain-f16 first layer reads the hi plane of each 64-channel group [hi | lo] of the pair-layout MuPS tensor
+      p.in_chunk_bytes = kRowBytes * (planes == 1 ? in_planes : 1);
       p.out_cstride = T.bufs[op.out_buf].C * (op.out_f32 ? 1 : planes); p.out_coff = op.out_coff;
       p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S; p.s_real = d.s_real;
       p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0; p.acc_scale = pl.acc_scale; p.x3native = pl.x3n ? 1 : 0;
@@ -802,15 +803,10 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C * planes; p.mp_mode = op.mp_mode; p.mp_mode2 = op.mp_mode2; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
-      if (pl.kind == 1) {   // conv8_kernel: feature bits for same-box A/B runs (bit 0: early staging of the next chunk)
-        static const int flags = [] { const char* e = getenv("NESTI_CONV8_FLAGS"); return e ? atoi(e) : 1; }();
-        p.remap = flags;
-      }
       const int cat = conv_category(d, pl);
       const int tok = prof_begin(cat, rc.stream);
-      const int rcv = pl.kind == 2   ? launch_conv8n(p, kernel_dtype(dtype), d.k, rc.stream)
-                      : pl.kind == 1 ? launch_conv8(p, kernel_dtype(dtype), d.k, rc.stream)
-                                     : launch_conv(p, kernel_dtype(dtype), pl.TN, rc.stream);
+      const int rcv = pl.kind == 2 ? launch_conv8n(p, kernel_dtype(dtype), d.k, rc.stream)
+                                   : launch_conv(p, kernel_dtype(dtype), pl.TN, rc.stream);
       prof_end(cat, tok, rc.stream);
       if (rcv) return 1;
     } else {
@@ -872,7 +868,7 @@ WsLayout ws_layout(const nesti_model* m, int NB) {
   if (m->cascade) {   // the f16 gate's logits, the flag list, [flag count | per-round counts]
     L.keep = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
     L.flags = o; o += align_up((size_t)NB * 4, 256);
-    L.fcounts = o; o += 512;
+    L.fcounts = o; o += 512;          // kernels.h: the two-stage gate's per-call counters
   }
   L.tower = o; o += max_tower_bytes(m, NB);
   L.total = o;
@@ -889,8 +885,7 @@ int gate_cascade(const nesti_model* m, const void* X0, int B, unsigned char* ws,
   const size_t tower_bytes_ = L.total - L.tower;
   float* keep = (float*)(ws + L.keep);
   int32_t* flag_list = (int32_t*)(ws + L.flags);
-  int32_t* flag_count = (int32_t*)(ws + L.fcounts);
-  int32_t* round_counts = flag_count + 8;
+  int32_t* fcounts = (int32_t*)(ws + L.fcounts);           // kernels.h: kRoundCountsOff, kTauEffOff, kWidenCountOff, kWidenRoundsOff
   const int lstride = m->graph.gate.bufs[m->graph.gate.out_buf].C;
   float* logits = nullptr;
   RunCtx fast{m, B, nullptr, nullptr, stream, /*fast=*/true};
@@ -898,15 +893,22 @@ int gate_cascade(const nesti_model* m, const void* X0, int B, unsigned char* ws,
   if (run_tower(fast, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
   prof_phase(NESTI_PHASE_RECHECK);
   const int cap = std::min(cascade_cap(NB), B), rounds = (B + cap - 1) / cap;
-  if (launch_gate_flag(logits, lstride, B, E, m->tau, probs, expert, keep, flag_count, flag_list, cap, rounds, round_counts,
+  if (launch_gate_flag(logits, lstride, B, E, m->tau, NESTI_GATE_WIDEN, probs, expert, keep, fcounts, flag_list, cap, rounds,
                        m->cstat, stream))
     return 1;
-  for (int r = 0; r < rounds; ++r) {
-    RunCtx exact{m, cap, round_counts + r, flag_list + (size_t)r * cap, stream};
-    if (run_tower(exact, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
-    if (launch_gate_recheck(logits, lstride, flag_list + (size_t)r * cap, round_counts + r, cap, E, keep, probs, expert,
-                            m->cstat, stream))
-      return 1;
+  // pass 0: the rows below the call's threshold; pass 1: the widening round -- the band between that threshold and
+  // NESTI_GATE_WIDEN x the largest error measured so far, pass 0's rows included (normally empty: its launches find a zero
+  // row count on the device and return; no host synchronisation, so the whole call stays graph-capturable)
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1 && launch_gate_widen(keep, B, E, NESTI_GATE_WIDEN, fcounts, flag_list, cap, rounds, m->cstat, stream)) return 1;
+    const int32_t* round_counts = fcounts + (pass == 0 ? kRoundCountsOff : kWidenRoundsOff);
+    for (int r = 0; r < rounds; ++r) {
+      RunCtx exact{m, cap, round_counts + r, flag_list + (size_t)r * cap, stream};
+      if (run_tower(exact, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
+      if (launch_gate_recheck(logits, lstride, flag_list + (size_t)r * cap, round_counts + r, cap, E, keep, probs, expert,
+                              m->cstat, stream))
+        return 1;
+    }
   }
   if (counts) return launch_route(expert, B, E, counts, lists, stream);
   return 0;
@@ -1045,12 +1047,16 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
   dtype = main_dtype(dtype);
   m->dtype = dtype;
   if (build_graph(cfg, &m->graph)) return 1;
-  if (conv8_selftest()) return 1;   // the 8^3 tap kernels' x padding relies on out-of-range LDS reads returning zero
   TensorTable tt;
   for (int i = 0; i < n_tensors; ++i) if (tensors[i].name) tt.by_name[tensors[i].name] = &tensors[i];
   m->packed.resize(m->graph.layers.size());
   for (size_t i = 0; i < m->graph.layers.size(); ++i)
     if (pack_layer(m->graph.layers[i], tt, dtype, &m->packed[i])) return 1;
+  // the 8^3 tap kernel's x padding relies on out-of-range LDS reads returning zero: checked once per device, and only for
+  // models that have such layers
+  bool any_conv8 = false;
+  for (const PackedLayer& pl : m->packed) any_conv8 = any_conv8 || pl.kind == 2;
+  if (any_conv8 && conv8_selftest()) return 1;
   if (m->cascade) {
     m->packed_fast.resize(m->graph.layers.size());
     for (const Op& op : m->graph.gate.ops)
@@ -1350,7 +1356,7 @@ int nesti_model_macs(const nesti_model_t* m, int tower, int kind, double* nomina
     const int parts = d.scope2.empty() ? 1 : 2;
     nom += (double)parts * V * d.k * d.k * d.k * d.cin * d.cout;
     use += (double)parts * valid * d.cin * d.cout;
-    // MFMA tiles the kernels issue: conv8_kernel (8^3) and the remapped conv_igemm_kernel layout at 4^3 hold one x-line
+    // MFMA tiles the kernels issue: conv8n_kernel (8^3) and the remapped conv_igemm_kernel layout at 4^3 hold one x-line
     // (y, z) per 32-row tile and skip it when y + dy or z + dz leaves the volume; elsewhere every kept tap is issued in full
     double tap_sum = pl.n_taps;
     const int Si = 1 << d.log2S;

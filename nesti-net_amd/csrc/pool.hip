@@ -165,23 +165,58 @@ __global__ void gate_finish_kernel(const float* __restrict__ logits, int lstride
 }
 
 // ---- NESTI_F16X3C: the two-stage gate (include/nesti_hip.h) -----------------------------------------------------------
-// cstat: device counters of the model: [0] queries, [1] rechecked, [2] changed, [3] bits of max_margin_err (a float >= 0
-// orders like its bit pattern), [4] a double: sum of the squared pair errors, [5] the number of pairs in that sum.
+// cstat: device counters of the model: [0] queries, [1] rechecked (rows decided by the f16x3 gate, widening round included),
+// [2] changed, [3] bits of max_margin_err (a float >= 0 orders like its bit pattern), [4] a double: sum of the squared pair
+// errors, [5] the number of pairs in that sum, [6] rows rechecked by a widening round, [7] forward calls whose widening round
+// was not empty.  The stats are accumulated with atomics in flag-list order, which is not deterministic: the double sum may
+// differ in its last bits from run to run (it only feeds sigma, a diagnostic and one input of the calibration).
+//
+// The margin REACTS to what the gate measures (it does not just report it): the threshold of a forward call is
+//   tau_eff = max(tau, NESTI_GATE_WIDEN * max_margin_err so far),
+// snapshotted into the call's workspace by gate_begin_kernel (forward calls on other streams share the counters and may raise
+// them while this one runs), and after the call's own recheck rounds gate_widen_kernel flags the band
+// [tau_eff, NESTI_GATE_WIDEN * max_margin_err) once more, so that an error the call has just measured is already covered for
+// the rows of the same call.  Unrechecked rows therefore keep a margin of at least NESTI_GATE_WIDEN x the largest error seen
+// on any row decided twice since the counters were last reset.
+__global__ void gate_begin_kernel(int32_t* __restrict__ fcounts, const unsigned long long* __restrict__ cstat, float tau,
+                                  float widen) {
+  if (threadIdx.x != 0) return;
+  fcounts[0] = 0;                                    // flag count of the filter pass
+  fcounts[kWidenCountOff] = 0;                       // ... of the widening round
+  const float m = __uint_as_float((unsigned)cstat[3]);
+  reinterpret_cast<float*>(fcounts)[kTauEffOff] = fmaxf(tau, widen * m);
+}
+
+__device__ __forceinline__ float top2_margin(const float* l, int E, bool* has_nan) {
+  float mx = -INFINITY, second = -INFINITY;
+  bool nan = false;
+  for (int e = 0; e < E; ++e) {
+    nan |= !(l[e] == l[e]);
+    if (l[e] > mx) { second = mx; mx = l[e]; } else second = fmaxf(second, l[e]);
+  }
+  *has_nan = nan;
+  return mx - second;
+}
+
 // Stage 1 (on the plain-f16 gate's logits): softmax + first-index arg-max like gate_finish_kernel; the logits are kept for
-// stage 2's error measurement and every row whose top-2 logit margin is below tau is appended to flag_list.
-__global__ void gate_flag_kernel(const float* __restrict__ logits, int lstride, int B, int E, float tau,
+// stage 2's error measurement and every row whose top-2 logit margin is below tau_eff -- or that holds a NaN logit (fmaxf and
+// the > comparisons above skip NaNs, so such a row could otherwise keep a large finite margin) -- is appended to flag_list.
+__global__ void gate_flag_kernel(const float* __restrict__ logits, int lstride, int B, int E,
                                  float* __restrict__ probs, int32_t* __restrict__ expert, float* __restrict__ keep,
-                                 int32_t* __restrict__ flag_count, int32_t* __restrict__ flag_list,
+                                 int32_t* __restrict__ fcounts, int32_t* __restrict__ flag_list,
                                  unsigned long long* __restrict__ cstat) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  float l[NESTI_MAX_EXPERTS], mx = -INFINITY, second = -INFINITY;
+  const float tau = reinterpret_cast<const float*>(fcounts)[kTauEffOff];
+  float l[NESTI_MAX_EXPERTS], mx = -INFINITY;
   for (int e = 0; e < E; ++e) {
     l[e] = logits[(size_t)b * lstride + e];
     keep[(size_t)b * NESTI_MAX_EXPERTS + e] = l[e];
-    if (l[e] > mx) { second = mx; mx = l[e]; } else second = fmaxf(second, l[e]);
+    mx = fmaxf(mx, l[e]);
   }
-  const bool flag = !(mx - second >= tau);   // a NaN margin is rechecked too
+  bool has_nan;
+  const float margin = top2_margin(l, E, &has_nan);
+  const bool flag = has_nan || !(margin >= tau);   // a NaN margin (inf - inf) is rechecked too
   float sum = 0.f;
   for (int e = 0; e < E; ++e) { l[e] = expf(l[e] - mx); sum += l[e]; }
   int best = 0;
@@ -192,13 +227,34 @@ __global__ void gate_flag_kernel(const float* __restrict__ logits, int lstride, 
     if (pr > pb) { pb = pr; best = e; }
   }
   expert[b] = best;
-  if (flag) flag_list[atomicAdd(flag_count, 1)] = b;
+  if (flag) flag_list[atomicAdd(&fcounts[0], 1)] = b;
   // one counter update per wave
   const unsigned long long fm = __ballot(flag), am = __ballot(true);
   if ((threadIdx.x & 63) == (unsigned)__ffsll((long long)am) - 1u) {
     atomicAdd(&cstat[0], (unsigned long long)__popcll(am));
     if (fm) atomicAdd(&cstat[1], (unsigned long long)__popcll(fm));
   }
+}
+
+// The widening round's flag list: rows whose f16 margin lies in [tau_eff, widen * max_margin_err) -- normally nobody.  Runs
+// after the call's recheck rounds, on the kept f16 logits; the first list is dead by then and its storage is reused.
+__global__ void gate_widen_kernel(const float* __restrict__ keep, int B, int E, float widen, int32_t* __restrict__ fcounts,
+                                  int32_t* __restrict__ flag_list, unsigned long long* __restrict__ cstat) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float lower = reinterpret_cast<const float*>(fcounts)[kTauEffOff];
+  const float upper = widen * __uint_as_float((unsigned)cstat[3]);
+  if (!(upper > lower)) return;
+  float l[NESTI_MAX_EXPERTS];
+  for (int e = 0; e < E; ++e) l[e] = keep[(size_t)b * NESTI_MAX_EXPERTS + e];
+  bool has_nan;
+  const float margin = top2_margin(l, E, &has_nan);
+  if (has_nan || !(margin >= lower && margin < upper)) return;    // NaN rows went through the first list
+  const int pos = atomicAdd(&fcounts[kWidenCountOff], 1);
+  flag_list[pos] = b;
+  atomicAdd(&cstat[1], 1ull);
+  atomicAdd(&cstat[6], 1ull);
+  if (pos == 0) atomicAdd(&cstat[7], 1ull);
 }
 
 // rows [r * cap, r * cap + cap) of list i are one round of a tower that runs `cap` rows at a time:
@@ -336,15 +392,26 @@ int launch_gate_finish(const float* logits, int lstride, int B, int E, float* pr
   return 0;
 }
 
-int launch_gate_flag(const float* logits, int lstride, int B, int E, float tau, float* probs, int32_t* expert, float* keep,
-                     int32_t* flag_count, int32_t* flag_list, int cap, int n_rounds, int32_t* round_counts,
-                     unsigned long long* cstat, hipStream_t stream) {
+int launch_gate_flag(const float* logits, int lstride, int B, int E, float tau, float widen, float* probs, int32_t* expert,
+                     float* keep, int32_t* fcounts, int32_t* flag_list, int cap, int n_rounds, unsigned long long* cstat,
+                     hipStream_t stream) {
   if (B <= 0) return 0;
-  if (E > NESTI_MAX_EXPERTS || n_rounds > 64) NESTI_FAIL("gate_flag: too many experts / rounds");
-  hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, stream, flag_count, 1);
-  hipLaunchKernelGGL(gate_flag_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, E, tau, probs,
-                     expert, keep, flag_count, flag_list, cstat);
-  hipLaunchKernelGGL(round_counts_kernel, dim3(1), dim3(64), 0, stream, flag_count, 1, cap, n_rounds, round_counts);
+  if (E > NESTI_MAX_EXPERTS || n_rounds > kMaxCascadeRounds) NESTI_FAIL("gate_flag: too many experts / rounds");
+  hipLaunchKernelGGL(gate_begin_kernel, dim3(1), dim3(64), 0, stream, fcounts, cstat, tau, widen);
+  hipLaunchKernelGGL(gate_flag_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, logits, lstride, B, E, probs,
+                     expert, keep, fcounts, flag_list, cstat);
+  hipLaunchKernelGGL(round_counts_kernel, dim3(1), dim3(64), 0, stream, fcounts, 1, cap, n_rounds, fcounts + kRoundCountsOff);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gate_widen(const float* keep, int B, int E, float widen, int32_t* fcounts, int32_t* flag_list, int cap, int n_rounds,
+                      unsigned long long* cstat, hipStream_t stream) {
+  if (B <= 0) return 0;
+  if (n_rounds > kMaxCascadeRounds) NESTI_FAIL("gate_widen: too many rounds");
+  hipLaunchKernelGGL(gate_widen_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, keep, B, E, widen, fcounts, flag_list, cstat);
+  hipLaunchKernelGGL(round_counts_kernel, dim3(1), dim3(64), 0, stream, fcounts + kWidenCountOff, 1, cap, n_rounds,
+                     fcounts + kWidenRoundsOff);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

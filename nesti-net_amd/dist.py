@@ -21,6 +21,19 @@ def max_shard(n_rows, world):
     return max(shard_range(n_rows, r, world)[1] - shard_range(n_rows, r, world)[0] for r in range(world))
 
 
+def agree_on_gate_margin(net, tau, device, group=None):
+    """dtype 'f16x3c': every rank calibrates its gate margin on the same sample, but sigma comes out of floating-point atomics
+    whose order differs from run to run, so the ranks' values may differ in their last bits.  All ranks adopt the largest one
+    (one scalar all-reduce, outside any timed region).  Returns (tau everyone uses, max - min over the ranks)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(tau), 0.0
+    t = torch.tensor([float(tau), -float(tau)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    hi, lo = float(t[0].item()), -float(t[1].item())
+    net.set_gate_margin(hi if hi < 1e30 else 1e30)
+    return hi, hi - lo
+
+
 _BUFFERS = {}
 
 

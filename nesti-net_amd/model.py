@@ -116,14 +116,17 @@ class NestiNet:
     def cascade_stats(self, reset=False, stream=None):
         """Counters of the two-stage gate since the last reset (synchronises the stream): dict with queries, rechecked,
         changed, max_margin_err (the f16 gate's largest error on a logit difference among the rechecked queries), sigma
-        (the standard deviation of that error over all rechecked (query, expert) pairs) and tau."""
+        (the standard deviation of that error over all rechecked (query, expert) pairs), tau, and the self-widening
+        counters: widened (queries re-decided by a widening round), widen_events (forward calls with a non-empty
+        widening round) and tau_eff = max(tau, 1.5 x max_margin_err), the threshold the next call starts from."""
         st = _lib.CCascadeStats()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.nesti_model_cascade_stats(self._handle, ctypes.byref(st), int(bool(reset)), self._stream(stream)),
                        "nesti_model_cascade_stats")
         sigma = (st.sum_sq_pair_err / st.pairs) ** 0.5 if st.pairs else 0.0
         return {"queries": int(st.queries), "rechecked": int(st.rechecked), "changed": int(st.changed),
-                "max_margin_err": float(st.max_margin_err), "sigma": float(sigma), "tau": float(st.tau)}
+                "max_margin_err": float(st.max_margin_err), "sigma": float(sigma), "tau": float(st.tau),
+                "widened": int(st.widened), "widen_events": int(st.widen_events), "tau_eff": float(st.tau_eff)}
 
     # -- workspace -------------------------------------------------------------------------
     def reserve(self, batch):

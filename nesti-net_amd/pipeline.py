@@ -33,28 +33,28 @@ class NormalEstimator:
             from .refsample import ReferencePatchSampler
             self._ref = ReferencePatchSampler(seed)
         self.use_graph = bool(use_graph)
-        # n_streams > 1: consecutive batches alternate between HIP streams (own staging buffers and scratch
-        # arena each), so one batch's partially filled last workgroup rounds overlap the other's kernels
-        self.n_streams = 1 if use_graph else max(1, int(n_streams))
-        # plain mode (one stream, no graph): ONE library call per run (nesti_estimate_normals) on one arena that holds
-        # the patch staging buffers and the forward workspace; the graph / multi-stream modes drive the batches from here
-        self._fused = not self.use_graph and self.n_streams == 1
+        # n_streams > 1: consecutive batches alternate between HIP streams (own scratch arena each), so one batch's partially
+        # filled last workgroup rounds overlap the other's kernels
+        self.n_streams = 1 if (use_graph or self._ref is not None) else max(1, int(n_streams))
+        # fused mode (everything but the hipGraph and reference-subsample modes): ONE library call per batch stream
+        # (nesti_estimate_normals / _multi: fused ball query + MuPS kernel, gate, routing, experts) on an arena that holds the
+        # staging buffers and the forward workspace; with one stream that is one call per run
+        self._fused = not self.use_graph and self._ref is None
         self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=1 if self._fused else self.batch)
         if gate_margin is not None:                       # dtype 'f16x3c' only (calibrate.calibrate_gate_margin picks one)
             self.net.set_gate_margin(gate_margin)
         S, P, E = cfg.n_scales, cfg.num_point, max(1, cfg.n_gate_out)
+        self._graph = None
         if self._fused:
             nbytes = self.net.lib.nesti_estimate_workspace_bytes(self.net._handle, self.batch)
             self._arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            self._lanes, self._graph = [], None
+            # lanes 1 .. n_streams - 1: (stream, arena); lane 0 is the caller's current stream with self._arena
+            self._lanes = [(torch.cuda.Stream(device=self.device), torch.empty(nbytes, dtype=torch.uint8, device=self.device))
+                           for _ in range(1, self.n_streams)]
             return
+        self._lanes = []
         self._points = torch.empty((self.batch, S * P, 3), dtype=torch.float32, device=self.device)
         self._n_eff = torch.empty((self.batch, S), dtype=torch.int32, device=self.device)
-        self._lanes = []
-        for i in range(1, self.n_streams):
-            self._lanes.append((torch.cuda.Stream(device=self.device), torch.empty_like(self._points),
-                                torch.empty_like(self._n_eff), self.net.new_workspace(self.batch)))
-        self._graph = None
         if self.use_graph:
             self._g_out = (torch.empty((self.batch, 3), dtype=torch.float32, device=self.device),
                            torch.empty((self.batch,), dtype=torch.int32, device=self.device),
@@ -99,36 +99,39 @@ class NormalEstimator:
         if self._ref is not None:
             return self._run_reference_order(cloud, first, count, normals, expert, probs, single_tower)
         if self._fused:
-            qidx = cloud.pidx[first:first + count].contiguous() if cloud.pidx is not None else None
-            st = torch.cuda.current_stream(self.device)
-            with torch.cuda.device(self.device):
-                _lib.check(self.net.lib.nesti_estimate_normals(
-                    self.net._handle, _lib.ptr(cloud.cloud), cloud.n_points, _lib.ptr(qidx), count, cloud._r,
-                    ctypes.c_uint64(cloud.seed), first, self.batch, 0, _lib.ptr(cloud._ws), cloud._ws.numel(),
-                    _lib.ptr(self._arena), self._arena.numel(), _lib.ptr(normals),
-                    None if single_tower else _lib.ptr(expert), None if single_tower else _lib.ptr(probs),
-                    ctypes.c_void_p(st.cuda_stream)), "nesti_estimate_normals")
+            main = torch.cuda.current_stream(self.device)
+            for st, _ in self._lanes:
+                st.wait_stream(main)                  # the cloud's grid (and earlier work) is ready
+            # one stream: ONE call, the library walks the batches; several: one call per batch, alternating the lanes
+            step = count if self.n_streams == 1 else self.batch
+            done, it = 0, 0
+            while done < count:
+                take = min(step, count - done)
+                lane = it % self.n_streams
+                it += 1
+                st, arena = (main, self._arena) if lane == 0 else self._lanes[lane - 1]
+                r0 = first + done
+                qidx = cloud.pidx[r0:r0 + take].contiguous() if cloud.pidx is not None else None
+                with torch.cuda.device(self.device):
+                    _lib.check(self.net.lib.nesti_estimate_normals(
+                        self.net._handle, _lib.ptr(cloud.cloud), cloud.n_points, _lib.ptr(qidx), take, cloud._r,
+                        ctypes.c_uint64(cloud.seed), r0, self.batch, 0, _lib.ptr(cloud._ws), cloud._ws.numel(),
+                        _lib.ptr(arena), arena.numel(), _lib.ptr(normals[done:done + take]),
+                        None if single_tower else _lib.ptr(expert[done:done + take]),
+                        None if single_tower else _lib.ptr(probs[done:done + take]),
+                        ctypes.c_void_p(st.cuda_stream)), "nesti_estimate_normals")
+                if qidx is not None and lane > 0:
+                    qidx.record_stream(st)
+                done += take
+            for st, _ in self._lanes:
+                main.wait_stream(st)                  # results are ordered on the caller's stream again
             if single_tower:
                 return normals, None, None
             return normals, expert, probs
-        done, it = 0, 0
-        main = torch.cuda.current_stream(self.device)
-        if self.n_streams > 1:
-            for lane in self._lanes:
-                lane[0].wait_stream(main)             # the cloud's grid (and earlier work) is ready
+        done = 0
         while done < count:
             take = min(self.batch, count - done)
             sl = slice(done, done + take)
-            lane = it % self.n_streams
-            it += 1
-            if lane > 0:
-                st, pb, nb, ws = self._lanes[lane - 1]
-                p, n = pb[:take], nb[:take]
-                with torch.cuda.stream(st):
-                    cloud.build(first + done, take, out=(p, n), stream=st)
-                    self.net.forward(p, n, out=(normals[sl], expert[sl], probs[sl]), stream=st, ws=ws)
-                done += take
-                continue
             p, n = self._points[:take], self._n_eff[:take]
             cloud.build(first + done, take, out=(p, n))
             if self.use_graph and take == self.batch:
@@ -142,8 +145,6 @@ class NormalEstimator:
             else:
                 self.net.forward(p, n, out=(normals[sl], expert[sl], probs[sl]))
             done += take
-        for lane in self._lanes:
-            main.wait_stream(lane[0])                 # results are ordered on the caller's stream again
         if single_tower:
             return normals, None, None
         return normals, expert, probs
@@ -171,8 +172,9 @@ class NormalEstimator:
         """Several shapes (or shards of shapes) as ONE stream of batches: ``items`` = [(cloud, first, count), ...].
         Returns one (normals, expert, probs) triple of device tensors per item (views of the concatenated outputs).
         Small shapes / shards share the gate and expert launches (``nesti_estimate_normals_multi``); results equal
-        ``run`` on each item.  8^3 grid, plain mode; otherwise falls back to per-item ``run``."""
-        if not self._fused or self.cfg.n_gaussians != 8 or self._ref is not None:
+        ``run`` on each item.  With ``n_streams`` > 1 the stream of rows is cut into groups of ``batch`` rows and the
+        groups alternate between the HIP streams.  8^3 grid, fused mode; otherwise falls back to per-item ``run``."""
+        if not self._fused or self.cfg.n_gaussians != 8:
             return [self.run(c, f, n) for c, f, n in items]
         total = sum(n for _, _, n in items)
         E = max(1, self.cfg.n_gate_out)
@@ -180,29 +182,56 @@ class NormalEstimator:
         normals = torch.empty((total, 3), dtype=torch.float32, device=self.device)
         expert = torch.empty((total,), dtype=torch.int32, device=self.device)
         probs = torch.empty((total, E), dtype=torch.float32, device=self.device)
-        arr = (_lib.CShapeQueries * max(1, len(items)))()
-        keep = []
-        for i, (cloud, first, count) in enumerate(items):
+        for cloud, first, count in items:
             if first < 0 or count < 0 or first + count > cloud.patch_count:
                 raise ValueError("patch rows [%d, %d) outside [0, %d)" % (first, first + count, cloud.patch_count))
-            qidx = cloud.pidx[first:first + count].contiguous() if cloud.pidx is not None else None
-            keep.append(qidx)
-            arr[i].cloud_dev = cloud.cloud.data_ptr()
-            arr[i].n_points = cloud.n_points
-            arr[i].query_idx_dev = qidx.data_ptr() if qidx is not None and count > 0 else None
-            arr[i].n_queries = count
-            for s, r in enumerate(cloud.r_abs):
-                arr[i].r_abs[s] = r
-            arr[i].seed = cloud.seed
-            arr[i].query_row0 = first
-            arr[i].grid_ws_dev = cloud._ws.data_ptr()
-            arr[i].grid_ws_bytes = cloud._ws.numel()
-        st = torch.cuda.current_stream(self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self.net.lib.nesti_estimate_normals_multi(
-                self.net._handle, arr, len(items), self.batch, _lib.ptr(self._arena), self._arena.numel(), _lib.ptr(normals),
-                None if single_tower else _lib.ptr(expert), None if single_tower else _lib.ptr(probs),
-                ctypes.c_void_p(st.cuda_stream)), "nesti_estimate_normals_multi")
+        # groups of pieces (cloud, first, count): one group = one library call on one lane
+        if self.n_streams == 1:
+            groups = [list(items)]
+        else:
+            groups, cur, room = [], [], self.batch
+            for cloud, first, count in items:
+                while count > 0:
+                    take = min(count, room)
+                    cur.append((cloud, first, take))
+                    first, count, room = first + take, count - take, room - take
+                    if room == 0:
+                        groups.append(cur)
+                        cur, room = [], self.batch
+            if cur:
+                groups.append(cur)
+        main = torch.cuda.current_stream(self.device)
+        for st, _ in self._lanes:
+            st.wait_stream(main)
+        keep, o = [], 0
+        for gi, group in enumerate(groups):
+            lane = gi % self.n_streams
+            st, arena = (main, self._arena) if lane == 0 else self._lanes[lane - 1]
+            arr = (_lib.CShapeQueries * max(1, len(group)))()
+            for i, (cloud, first, count) in enumerate(group):
+                qidx = cloud.pidx[first:first + count].contiguous() if cloud.pidx is not None else None
+                if qidx is not None and lane > 0:
+                    qidx.record_stream(st)
+                keep.append(qidx)
+                arr[i].cloud_dev = cloud.cloud.data_ptr()
+                arr[i].n_points = cloud.n_points
+                arr[i].query_idx_dev = qidx.data_ptr() if qidx is not None and count > 0 else None
+                arr[i].n_queries = count
+                for s, r in enumerate(cloud.r_abs):
+                    arr[i].r_abs[s] = r
+                arr[i].seed = cloud.seed
+                arr[i].query_row0 = first
+                arr[i].grid_ws_dev = cloud._ws.data_ptr()
+                arr[i].grid_ws_bytes = cloud._ws.numel()
+            rows = sum(c for _, _, c in group)
+            with torch.cuda.device(self.device):
+                _lib.check(self.net.lib.nesti_estimate_normals_multi(
+                    self.net._handle, arr, len(group), self.batch, _lib.ptr(arena), arena.numel(), _lib.ptr(normals[o:o + rows]),
+                    None if single_tower else _lib.ptr(expert[o:o + rows]), None if single_tower else _lib.ptr(probs[o:o + rows]),
+                    ctypes.c_void_p(st.cuda_stream)), "nesti_estimate_normals_multi")
+            o += rows
+        for st, _ in self._lanes:
+            main.wait_stream(st)
         out, o = [], 0
         for _, _, n in items:
             out.append((normals[o:o + n], None if single_tower else expert[o:o + n], None if single_tower else probs[o:o + n]))

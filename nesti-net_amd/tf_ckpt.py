@@ -95,11 +95,51 @@ def _parse_entry(buf):
 _MASK_DELTA = 0xa282ead8
 
 
+_CRC_TABLES = None
+
+
+def _crc_tables():
+    """Slicing-by-8 tables of the Castagnoli polynomial (reflected 0x82F63B78), built once with numpy."""
+    global _CRC_TABLES
+    if _CRC_TABLES is None:
+        t0 = np.arange(256, dtype=np.uint32)
+        for _ in range(8):
+            t0 = np.where(t0 & 1, (t0 >> 1) ^ np.uint32(0x82F63B78), t0 >> 1).astype(np.uint32)
+        tabs = [t0]
+        for _ in range(7):
+            prev = tabs[-1]
+            tabs.append((t0[prev & 0xff] ^ (prev >> 8)).astype(np.uint32))
+        _CRC_TABLES = [t.tolist() for t in tabs]
+    return _CRC_TABLES
+
+
+def crc32c_py(data, crc=0):
+    """CRC-32C without the native library (slicing-by-8 over table lookups; ~10 MB/s -- fine for index blocks, slow for the
+    ~400 MB of tensor data of a full checkpoint)."""
+    t = _crc_tables()
+    buf = bytes(data) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).tobytes()
+    c = (~crc) & 0xffffffff
+    n8 = len(buf) // 8 * 8
+    t0, t1, t2, t3, t4, t5, t6, t7 = t
+    for lo, hi in struct.iter_unpack("<II", buf[:n8]):
+        lo ^= c
+        c = (t7[lo & 0xff] ^ t6[(lo >> 8) & 0xff] ^ t5[(lo >> 16) & 0xff] ^ t4[lo >> 24] ^
+             t3[hi & 0xff] ^ t2[(hi >> 8) & 0xff] ^ t1[(hi >> 16) & 0xff] ^ t0[hi >> 24])
+    for b in buf[n8:]:
+        c = t0[(c ^ b) & 0xff] ^ (c >> 8)
+    return (~c) & 0xffffffff
+
+
 def crc32c(data, crc=0):
-    """CRC-32C of bytes / a contiguous uint8 array (native: ``nesti_crc32c`` of libnesti_hip.so, host code)."""
+    """CRC-32C of bytes / a contiguous uint8 array: ``nesti_crc32c`` of libnesti_hip.so (host code) when the library can be
+    loaded, the pure-Python routine otherwise -- reading a checkpoint's index must not depend on the ROCm runtime."""
     from . import _lib
+    try:
+        lib = _lib.load()
+    except (OSError, _lib.NestiError):
+        return crc32c_py(data, crc)
     buf = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
-    return int(_lib.load().nesti_crc32c(_lib.ptr(buf) if buf.size else None, buf.size, crc))
+    return int(lib.nesti_crc32c(_lib.ptr(buf) if buf.size else None, buf.size, crc))
 
 
 def mask_crc(crc):
@@ -119,7 +159,9 @@ def _read_block(data, offset, size, verify=True):
     if ctype != 0:
         raise ValueError("compressed table blocks (type %d) are not supported" % ctype)
     stored = struct.unpack("<I", data[offset + size + 1:offset + size + 5])[0]
-    if verify and stored != 0 and unmask_crc(stored) != crc32c(data[offset:offset + size + 1]):
+    # a table block ALWAYS carries its trailer (leveldb's BlockBuilder / TF's table_builder.cc write it unconditionally), so a
+    # zeroed field is a corrupt block, not an absent checksum (unlike the optional crc32c field of a BundleEntryProto)
+    if verify and unmask_crc(stored) != crc32c(data[offset:offset + size + 1]):
         raise ValueError("table block at offset %d fails its crc32c" % offset)
     n_restarts = struct.unpack("<I", raw[-4:])[0]
     end = len(raw) - 4 - 4 * n_restarts

@@ -5,6 +5,7 @@ import socket
 import numpy as np
 import torch
 import torch.distributed as dist
+import pytest
 import torch.multiprocessing as mp
 
 from conftest import REPO
@@ -72,19 +73,62 @@ def _worker_many(rank, world, port, sizes, q):
     dist.destroy_process_group()
 
 
-def test_sharded_many_two_ranks_gloo():
+class _FakeNet:
+    def __init__(self):
+        self.tau = None
+
+    def set_gate_margin(self, tau):
+        self.tau = tau
+
+
+def _worker_margin(rank, world, port, q):
+    import sys
+    sys.path.insert(0, REPO)
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import dist as nd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _FakeNet()
+    tau, spread = nd.agree_on_gate_margin(net, 0.147 + 1e-9 * rank, torch.device("cpu"))
+    q.put((rank, tau, spread, net.tau))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_every_rank_adopts_the_same_gate_margin_world_8():
+    """The ranks' calibrated margins may differ in their last bits (atomics); all of them must end up filtering with ONE value."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_margin, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    taus = {t for _, t, _, _ in res}
+    assert len(taus) == 1 and abs(taus.pop() - (0.147 + 7e-9)) < 1e-12
+    assert all(abs(s - 7e-9) < 1e-12 and nt == t for _, t, s, nt in res)
+
+
+@pytest.mark.parametrize("sizes,world", [([1001, 64, 500], 2),
+                                         # world size 8 (the north star's node): sizes not divisible by 8, a cloud with fewer
+                                         # rows than ranks (three ranks get nothing of it), an empty cloud, equal shards
+                                         ([100003, 5, 12501, 0, 64], 8)])
+def test_sharded_many_gloo(sizes, world):
     """One all-gather for several clouds of different (ragged) sizes: every rank ends up with every cloud in row order."""
-    sizes, world = [1001, 64, 500], 2
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker_many, args=(r, world, port, sizes, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == list(range(world))
     for rank, clouds in res:
         for n_rows, (n, e, p) in zip(sizes, clouds):
             rows = np.arange(n_rows, dtype=np.float32) + 1000.0 * n_rows
@@ -104,12 +148,9 @@ def test_shard_ranges_cover_everything():
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
 
 
-import pytest
-
-
-@pytest.mark.parametrize("n_rows", [1001, 1000])      # ragged (shards of 500 and 501) and equal shards
-def test_gather_two_ranks_gloo(n_rows):
-    world = 2
+@pytest.mark.parametrize("n_rows,world", [(1001, 2), (1000, 2),      # ragged (shards of 500 and 501) and equal shards
+                                          (100003, 8), (5, 8)])     # the 8-GPU node: ragged, and fewer rows than ranks
+def test_gather_gloo(n_rows, world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

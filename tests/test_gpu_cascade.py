@@ -85,12 +85,97 @@ def test_calibrated_margin_reproduces_the_f16x3_decisions(case, gpu_device):
     st = net.cascade_stats()
     print("tau", tau, st, "f16 gate flips", int((e16 != ref[1]).sum().item()))
     assert st["queries"] == B and 0 < st["rechecked"] < B // 2          # a filter, not a second full pass
-    assert st["max_margin_err"] < 0.8 * tau and tau >= 6.9 * st["sigma"]   # what tau rests on, re-measured on this batch
+    assert tau >= 6.9 * st["sigma"]                                     # what tau rests on, re-measured on this batch
+    # the margin protects itself (NESTI_GATE_WIDEN): whatever this batch measured, every unrechecked row kept a margin of at
+    # least 1.5 x the largest error, either because tau already was that large or because a widening round re-decided the band
+    assert st["tau_eff"] == pytest.approx(max(tau, 1.5 * st["max_margin_err"]), rel=1e-6)
+    assert (st["widen_events"] > 0) == (st["widened"] > 0)
+    if st["max_margin_err"] <= tau / 1.5:
+        assert st["widened"] == 0 and st["tau_eff"] == pytest.approx(tau)
     assert torch.equal(expert, ref[1]) and torch.equal(normals, ref[0])
     # probabilities: f16x3's on the rechecked rows, the f16 gate's elsewhere
     same = (probs == ref[2]).all(dim=1)
     assert int(same.sum().item()) >= st["rechecked"]
     assert torch.equal(probs[~same], p16[~same])
+
+
+def test_margin_widens_itself_when_the_measured_error_approaches_it(case, gpu_device):
+    """A margin that is too small for the data does not just show up in the statistics: the first call measures the f16
+    gate's error on the rows it decides twice and re-decides, in the same call, the rows whose margin lies between tau and
+    1.5 x that error (widened > 0, widen_events == 1); the next call starts from the raised threshold and needs no widening
+    round.  Rows that still keep the f16 arg-max have a margin of at least 1.5 x the largest error measured."""
+    from nesti_net_amd.model import NestiNet
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
+    tau = 0.02                                                          # far below the f16 gate's error on this data (~0.1)
+    net.set_gate_margin(tau)
+    net.cascade_stats(reset=True)
+    normals, expert, probs = net(points, n_eff)
+    st1 = net.cascade_stats()
+    print("first call", st1)
+    assert st1["tau"] == pytest.approx(tau) and st1["max_margin_err"] > tau / 1.5
+    assert st1["widen_events"] == 1 and 0 < st1["widened"] < st1["rechecked"] <= B
+    assert st1["tau_eff"] == pytest.approx(1.5 * st1["max_margin_err"], rel=1e-6)
+    # every row with an f16 margin below 1.5 x the error known when the widening round ran was decided by the f16x3 gate:
+    # its outputs are f16x3's bit for bit; the others keep the f16 gate's (and may differ from f16x3 only through its error)
+    l16 = torch.log(p16.double())
+    srt = torch.sort(l16, dim=1, descending=True).values
+    margin16 = (srt[:, 0] - srt[:, 1]).cpu().numpy()                    # = the f16 logit margin (softmax is shift-invariant)
+    decided_twice = (probs == ref[2]).all(dim=1).cpu().numpy()
+    assert decided_twice.sum() >= st1["rechecked"]
+    assert np.all(margin16[~decided_twice] >= tau - 1e-4)
+    assert torch.equal(expert[torch.as_tensor(decided_twice)], ref[1][torch.as_tensor(decided_twice)])
+    flips = int((expert != ref[1]).sum().item())
+    assert flips <= int((e16 != ref[1]).sum().item())
+    # second call: the threshold already is tau_eff -- the same rows (and more) go through the first list, nothing is widened
+    net.cascade_stats(reset=False)
+    normals2, expert2, probs2 = net(points, n_eff)
+    st2 = net.cascade_stats()
+    print("second call", st2)
+    if st2["max_margin_err"] == st1["max_margin_err"]:
+        assert st2["widen_events"] == 1 and st2["widened"] == st1["widened"]
+    assert st2["rechecked"] - st1["rechecked"] >= st1["rechecked"]
+    assert int((expert2 != ref[1]).sum().item()) <= flips
+    # resetting the counters forgets the measured error: the threshold is tau again
+    net.cascade_stats(reset=True)
+    assert net.cascade_stats()["tau_eff"] == pytest.approx(tau)
+
+
+def test_four_scale_filter_pass_reads_both_channel_groups(gpu_device):
+    """n_scales = 4: the MuPS tensor has 80 channels = TWO 64-channel groups, which the pair layout stores as
+    [hi0 | lo0 | hi1 | lo1]; the plain-f16 filter pass must read hi0 and hi1 (ConvParams::in_chunk_bytes), not hi0 and lo0.
+    With tau = 0 the filter pass IS the whole gate, so its outputs must equal the plain-f16 model's gate bit for bit."""
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    cfg = NestiConfig(patch_radius=[0.01, 0.02, 0.04, 0.06], num_point=128, n_experts=8, expert_dict=None)
+    cfg.expert_dict = cfg.default_expert_dict()
+    W = weights.synthetic_weights(cfg)
+    rng = np.random.RandomState(11)
+    Bq = 37
+    pts = ((rng.rand(Bq, 4 * 128, 3) - 0.5) * 1.6).astype(np.float32)
+    n_eff = rng.randint(20, 129, size=(Bq, 4)).astype(np.int32)
+    for b in range(Bq):
+        for s_ in range(4):
+            pts[b, 128 * s_ + n_eff[b, s_]:128 * (s_ + 1)] = 0
+    p, n = torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device)
+    f16 = NestiNet(cfg, W, dtype="f16", device=gpu_device, max_batch=Bq)
+    p16, e16 = f16.gate(f16.mups(p, n))
+    net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=Bq)
+    assert net.mups_cstride == 2 * 128
+    net.set_gate_margin(0.0)
+    pc, ec = net.gate(net.mups(p, n))
+    assert torch.equal(pc, p16) and torch.equal(ec, e16)
+    # and scale 4 really reaches the gate: zeroing its patches changes the f16 probabilities
+    pts0 = pts.copy()
+    pts0[:, 3 * 128:] = 0
+    p0, _ = f16.gate(f16.mups(torch.as_tensor(pts0, device=gpu_device), n))
+    assert not torch.equal(p0, p16)
+    # with tau = inf the mode is f16x3
+    x3 = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=Bq)
+    net.set_gate_margin(1e30)
+    for a, b in zip(net(p, n), x3(p, n)):
+        assert torch.equal(a, b)
 
 
 def test_product_path_batches_graph_and_stream_modes_agree(case, gpu_device):

@@ -101,7 +101,11 @@ def test_f32_path_matches_oracle_across_fixture_cloud(name, gpu_device):
     print(name, "routing", np.bincount(ex, minlength=cfg.n_experts), "prob err", perr, "flips", int((~agree).sum()),
           "min margin", margin.min(), "1-cos max", (1 - c).max())
     assert len(np.unique(ex)) >= min(5, cfg.n_experts)
-    assert perr < 1e-4                                 # the calibrated gate's last layer amplifies logit differences
+    # the bound parity.TIE_MARGIN is derived from (2 x it): the f32 mode's probabilities against the fp64 oracle's on
+    # every query of every fixture cloud; the calibrated gate's last layer amplifies logit differences
+    from nesti_net_amd import parity
+    print(name, "F32_PROB_ERR on this fixture %.4g (bound %.4g, TIE_MARGIN %.4g)" % (perr, parity.F32_PROB_ERR_BOUND, parity.TIE_MARGIN))
+    assert perr <= parity.F32_PROB_ERR_BOUND
     assert np.all(agree | (margin < 2e-5))            # arg-max exact unless the fp64 oracle's own top-2 are tied to 2e-5
     assert np.all(1 - c < 1e-5)
     # ---- the same rows in the f16x3 pair mode (the north-star mode of the bench) against the same oracle results ----
@@ -115,6 +119,27 @@ def test_f32_path_matches_oracle_across_fixture_cloud(name, gpu_device):
     assert perr3 < 1e-4
     assert np.all(agree3 | (margin < 2e-5))
     assert np.all(1 - c3 < 1e-5)
+    # ---- ... and in f16x3c, the headline mode: f16x3 behind the two-stage gate, its margin calibrated on this fixture's own
+    # queries (>= 256, as bench.py does on the timed cloud), against the SAME fp64 oracle results ------------------------------
+    from nesti_net_amd.calibrate import calibrate_gate_margin
+    net_c = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=len(q))
+    tau = calibrate_gate_margin(net_c, p_d, n_d)
+    nc, ec, pc = net_c(p_d, n_d)
+    st = net_c.cascade_stats()
+    agree_c = ec.cpu().numpy() == ref["expert"]
+    perr_c = np.abs(pc.cpu().numpy() - ref["probs"])
+    cc = _cos(nc.cpu().numpy()[agree_c], ref["normals"][agree_c])
+    twice = (pc == p3).all(dim=1).cpu().numpy()              # rows decided by the f16x3 gate carry its probabilities
+    print(name, "f16x3c: tau %.4g" % tau, st, "flips", int((~agree_c).sum()), "prob err (rechecked rows / all)",
+          perr_c[twice].max() if twice.any() else 0.0, perr_c.max(), "1-cos max", (1 - cc).max())
+    assert np.isfinite(tau) and 0 < st["rechecked"] < len(q) and st["queries"] == len(q)
+    assert np.all(agree_c | (margin < 2e-5))                 # arg-max exact against the oracle, like f32 and f16x3 above
+    assert np.array_equal(ec.cpu().numpy(), e3.cpu().numpy())   # ... and identical to f16x3's on every query
+    assert torch.equal(nc, n3)                               # the experts always run in f16x3
+    assert np.all(1 - cc < 1e-5)
+    assert twice.sum() >= st["rechecked"] and (not twice.any() or perr_c[twice].max() < 1e-4)
+    assert perr_c.max() < 0.05                               # unrechecked rows carry the f16 gate's probabilities
+    assert st["max_margin_err"] * 1.5 <= st["tau_eff"] * (1 + 1e-6)
 
 
 @pytest.fixture(scope="module")

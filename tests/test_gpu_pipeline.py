@@ -87,6 +87,36 @@ def test_cli_writes_reference_file_contract(dataset_dir, tmp_path, gpu_device):
     assert set(per_shape) == {"shapeA", "shapeB"} and 0 <= avg["rms"] <= 90 and 0 <= avg["pgp10"] <= 1
 
 
+def test_cli_default_mode_calibrates_the_gate_per_shape(dataset_dir, tmp_path, gpu_device):
+    """--dtype auto = f16x3c for experts_n_est: the gate margin is calibrated on every shape (its counters are that shape's,
+    printed to log.txt), two library batches are in flight on two streams, and .normals / .experts equal the f16x3 mode's."""
+    from nesti_net_amd import weights
+    from nesti_net_amd.cli import main
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.pipeline import NormalEstimator
+    from nesti_net_amd.provider import load_xyz
+    results = str(tmp_path / "log") + os.sep
+    cfg = NestiConfig()
+    W = weights.synthetic_weights(cfg)
+    os.makedirs(results)
+    weights.save(os.path.join(results, "model.nstw"), W, cfg)
+    rc = main(["--results_path", results, "--dataset_name", "synth", "--dataset_path", dataset_dir, "--testset", "testset.txt"])
+    assert rc == 0
+    out = os.path.join(results, "synth_results")
+    log = open(os.path.join(out, "log.txt")).read()
+    assert log.count("gate margin for shape") == 2 and log.count("two-stage gate on shape") == 2
+    est = NormalEstimator(cfg, W, dtype="f16x3", device=gpu_device, batch=1000)
+    for nm, n in (("shapeA", 3000), ("shapeB", 2500)):
+        normals = np.loadtxt(os.path.join(out, nm + ".normals"))
+        experts = np.loadtxt(os.path.join(out, nm + ".experts"))
+        probs = np.loadtxt(os.path.join(out, nm + ".experts_probs"))
+        assert normals.shape == (n, 3) and experts.shape == (n,) and probs.shape == (n, 7)
+        n2, e2, p2 = est.estimate(load_xyz(os.path.join(dataset_dir, nm + ".xyz")))
+        assert np.array_equal(e2, experts.astype(np.int32))
+        assert np.array_equal(n2.astype(np.float64), normals)
+        assert np.abs(p2 - probs).max() < 0.05
+
+
 def test_hipgraph_replay_matches_eager(gpu_device):
     """BASELINE config 4 ingredient: the captured forward (hipGraph) replays bit-identically, in f16, over a
     stream of clouds of different density without host synchronisation in between.  The gate is calibrated so that

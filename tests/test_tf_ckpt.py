@@ -124,6 +124,12 @@ def test_crc32c_known_answers_and_masked_form():
         assert tf_ckpt.crc32c(blob[cut:], tf_ckpt.crc32c(blob[:cut])) == crc32c_py(blob)
     arr = np.frombuffer(blob, np.uint8)
     assert tf_ckpt.crc32c(arr[3:997]) == crc32c_py(blob[3:997])
+    # the reader's pure-Python fallback (used when libnesti_hip.so cannot be loaded): same vectors, chaining, odd tails
+    for data, want in vectors:
+        assert tf_ckpt.crc32c_py(data) == want
+    assert tf_ckpt.crc32c_py(b"123456789") == 0xe3069283
+    for cut in (0, 1, 7, 8, 9, 500, 999, 1000):
+        assert tf_ckpt.crc32c_py(blob[cut:], tf_ckpt.crc32c_py(blob[:cut])) == crc32c_py(blob)
     # crc32c::Mask: rotate right 15, add 0xa282ead8 (mod 2^32)
     assert tf_ckpt.mask_crc(0) == 0xa282ead8 and tf_ckpt.mask_crc(0xe3069283) == 0xc78ab0e5 == masked(0xe3069283)
     for c in (0, 1, 0x8a9136aa, 0xffffffff, 0x5d7d1528):
@@ -162,6 +168,9 @@ def test_prefix_compressed_block_and_footer_by_hand(tmp_path):
     # a flipped byte must be caught by the block checksum
     bad = bytearray(block + b"\x00" + struct.pack("<I", tf_ckpt.mask_crc(tf_ckpt.crc32c(block + b"\x00"))))
     bad[20] ^= 0x40
+    zeroed = block + b"\x00" + b"\x00\x00\x00\x00"                                # a table block always carries its trailer:
+    with pytest.raises(ValueError, match="crc32c"):                                # an all-zero one is corruption, not "absent"
+        tf_ckpt._read_block(zeroed, 0, len(block))
     with pytest.raises(ValueError, match="crc32c"):
         tf_ckpt._read_block(bytes(bad), 0, len(block))
     # the smallest table: data block, empty metaindex block, index block, 48-byte footer ending in the LevelDB magic
