@@ -422,9 +422,10 @@ def main():
     main_run = timed_run(args, cfg, W, clouds_np, args.dtype, args.steps, args.warmup, dev, world, rank, use_pg,
                          timing and args.streams == 1, want_shard0=not args.no_parity and args.dtype != "f32", streams=args.streams)
     # per-kernel times need launches that do not overlap: a short single-stream pass of the same workload carries the roofline
+    # (every rank takes part -- the pass contains the same collectives as the headline run -- but only rank 0 records events)
     roof_run = main_run
-    if timing and main_run["streams"] > 1:
-        roof_run = timed_run(args, cfg, W, clouds_np, args.dtype, 2, 1, dev, world, rank, use_pg, True, want_shard0=False)
+    if not args.no_kernel_timing and main_run["streams"] > 1:
+        roof_run = timed_run(args, cfg, W, clouds_np, args.dtype, 2, 1, dev, world, rank, use_pg, timing, want_shard0=False)
     strong = None
     if headline and (world > 1 or args.strong):
         strong = timed_run(args, cfg, W, clouds_np, args.dtype, max(2, min(args.steps, 5)), 1, dev, world, rank, use_pg, False,

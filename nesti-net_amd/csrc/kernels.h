@@ -28,6 +28,7 @@ struct ConvParams {
                        // input row -- 128, or 256 when a plain-f16 layer reads the hi planes of a pair-layout tensor (model.hip)
   int out_cstride, out_coff;
   int n_chunks, n_taps;
+  int tap_k;           // kernel edge k when all k^3 taps are present in x-fastest order (conv4n_kernel derives the taps from counters)
   int log2S;           // S in {1,2,4,8}: the index space rows are laid out in
   int s_real;          // 0, or the real volume edge when it is smaller than S (3^3 Gaussian grid embedded in 4^3:
                        // voxels with a coordinate >= s_real are dead rows -- never read as neighbours, contents ignored)
@@ -66,6 +67,10 @@ int launch_conv8(const ConvParams& p, int dtype, int k, hipStream_t stream);
 // the same layers with A-fragment reuse (conv8n.hip): a workgroup = 4 points x one z half x 64 columns; p.n_tiles = 64-column
 // pairs, weights packed [pair][chunk][tap][2 x 32 rows][64 B]
 int launch_conv8n(const ConvParams& p, int dtype, int k, hipStream_t stream);
+// k^3 taps (k = 2 .. 5) on the 4^3 volume (conv4n.hip): a workgroup = 16 points x 64 voxels x 64 columns, an MFMA tile = one voxel of
+// 16 points; p.m_tiles = groups of 16 points, p.n_tiles = 64-column tiles, p.n_chunks = 64-byte K chunks, weights packed
+// [n tile][chunk][tap][64 rows][64 B]
+int launch_conv4n(const ConvParams& p, int dtype, int k, hipStream_t stream);
 // conv8_kernel / conv8n_kernel read the x padding from an LDS address beyond the workgroup's allocation and rely on the
 // hardware returning zeros there (gfx950 does: scripts/lds_oob_probe.hip).  Checked once per device, at model creation:
 // the device must be gfx950 and a probe kernel must read zeros; otherwise the model is refused (returns 1 with a message).

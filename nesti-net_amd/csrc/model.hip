@@ -423,7 +423,7 @@ struct PackedLayer {
   float* bias = nullptr;
   int TN = 64, n_tiles = 0, split_tile = 0, n_chunks = 0, n_taps = 0;
   int kind = 0;              // 0: conv_igemm_kernel (conv.hip), 2: conv8n_kernel (conv8n.hip: 4 points x a z half x 64 columns
-                             // per workgroup)
+                             // per workgroup), 3: conv4n_kernel (conv4n.hip: 16 points x 64 voxels x 64 columns)
   bool x3n = false;          // pair modes: K chunks [hi | lo] / [W_hi | W_lo], three MFMAs per fragment set
   float acc_scale = 1.0f;    // 2^-s when the packed weights carry a 2^s scale (NESTI_F16X3)
   int8_t tap[kMaxTaps][4];
@@ -522,6 +522,11 @@ bool use_conv8(const LayerDesc& d) {
   if (d.is_fc || d.log2S != 3 || d.s_real || !d.scope2.empty()) return false;
   return d.k == 5 || d.k == 3;
 }
+// ... and on conv4n_kernel (conv4n.hip): the k^3 taps (k = 2 .. 5) on the 4^3 volume (not the 3^3 grid embedded in 4^3)
+bool use_conv4(const LayerDesc& d, int dtype) {
+  if (d.is_fc || d.log2S != 2 || d.s_real || !d.scope2.empty() || d.k < 2 || d.k > 5) return false;
+  return act_planes(dtype) == 1 || !(d.k & 1);   // pair modes: the even kernels only (conv4n.hip: launch_conv4n_dt)
+}
 
 // Error attribution in the pair modes (scripts/exp_attribution.py), ONLY in builds made with -DNESTI_ATTRIBUTION (the product
 // library has no such switch): NESTI_X3_PLAIN = "regex,regex,..." -- a layer whose scope matches drops the hi * W_lo product
@@ -581,14 +586,14 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
   // plain chunk holds (the kernels' pair K loop multiplies hi*W_hi + lo*W_hi + hi*W_lo from it: conv.hip / conv8n.hip, X3)
   const int planes = act_planes(dtype);
   const int drop = planes > 1 ? x3_drop_mask(d) : 0;
-  pl->kind = use_conv8(d) ? 2 : 0;
-  if (pl->kind == 2 && d.Cout_p % 64) NESTI_FAIL("internal: conv8n_kernel needs 64-column tile pairs");
+  pl->kind = use_conv8(d) ? 2 : use_conv4(d, dtype) ? 3 : 0;
+  if (pl->kind >= 2 && d.Cout_p % 64) NESTI_FAIL("internal: conv8n_kernel / conv4n_kernel need 64-column tiles");
   pl->x3n = planes > 1;
   const int K_phys = d.Cin_p * planes;
   const int row_bytes = pl->kind >= 1 ? 64 : kRowBytes;   // bytes of one K chunk of one row
   const int KC = row_bytes / (int)esz;
   const int chunk_ch = KC / planes;                       // input channels per K chunk
-  pl->TN = pl->kind == 2 ? 64 : (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
+  pl->TN = pl->kind >= 2 ? 64 : (part_p % 128 == 0) ? 128 : 64;   // a tile never straddles the two parts
   pl->n_tiles = d.Cout_p / pl->TN;
   pl->split_tile = part_p / pl->TN * (n_parts == 2 ? 1 : n_parts);
   if (n_parts == 1) pl->split_tile = pl->n_tiles;
@@ -643,9 +648,11 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
             const int n = n_base + nl;
             if (n >= d.cout) break;
             const float v = wrow[n] * f.scale[n] * wmul;
-            // the kernels' LDS image: row nl, 16-B slot XOR-swizzled (conv8n_kernel: 64-B rows, key (row >> 2) & 3)
+            // the kernels' LDS image: row nl, 16-B slot XOR-swizzled (conv8n_kernel: 64-B rows, key (row >> 2) & 3;
+            // conv4n_kernel: 64-B rows, key {0, 2, 3, 1}[(row >> 2) & 3])
+            const int key64 = pl->kind == 3 ? (0x78 >> (2 * ((nl >> 2) & 3))) & 3 : (nl >> 2) & 3;
             unsigned char* dst = pl->kind >= 1
-                ? tile + (size_t)nl * 64 + ((slot ^ ((nl >> 2) & 3)) << 4) + within * esz
+                ? tile + (size_t)nl * 64 + ((slot ^ key64) << 4) + within * esz
                 : tile + (size_t)nl * kRowBytes + ((slot ^ ((nl >> 1) & 7)) << 4) + within * esz;
             if (dtype == NESTI_F32) memcpy(dst, &v, 4);
             else if (planes > 1) {
@@ -753,7 +760,7 @@ int conv_remap(int k, int log2S, int n_taps) {
 
 // which NESTI_PROF_* conv category a layer's launch is booked under
 int conv_category(const LayerDesc& d, const PackedLayer& pl) {
-  if (pl.kind >= 1) return d.k == 5 ? NESTI_PROF_CONV8_K5 : NESTI_PROF_CONV8_K3;
+  if (pl.kind == 2) return d.k == 5 ? NESTI_PROF_CONV8_K5 : NESTI_PROF_CONV8_K3;
   return pl.n_taps > 1 ? NESTI_PROF_TAPS : NESTI_PROF_ONE_BY_ONE;
 }
 
@@ -795,18 +802,19 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       // whose plain-f16 first layer reads the hi plane of each 64-channel group [hi | lo] of the pair-layout MuPS tensor
       p.in_chunk_bytes = kRowBytes * (planes == 1 ? in_planes : 1);
       p.out_cstride = T.bufs[op.out_buf].C * (op.out_f32 ? 1 : planes); p.out_coff = op.out_coff;
-      p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.log2S = d.log2S; p.s_real = d.s_real;
+      p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.tap_k = d.k; p.log2S = d.log2S; p.s_real = d.s_real;
       p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0; p.acc_scale = pl.acc_scale; p.x3native = pl.x3n ? 1 : 0;
       const long long rows = (long long)rc.NB << (3 * d.log2S);
-      p.m_tiles = pl.kind >= 1 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
+      p.m_tiles = pl.kind == 3 ? (rc.NB + 15) / 16 : pl.kind == 2 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
       if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C * planes; p.mp_mode = op.mp_mode; p.mp_mode2 = op.mp_mode2; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
       const int cat = conv_category(d, pl);
       const int tok = prof_begin(cat, rc.stream);
-      const int rcv = pl.kind == 2 ? launch_conv8n(p, kernel_dtype(dtype), d.k, rc.stream)
-                                   : launch_conv(p, kernel_dtype(dtype), pl.TN, rc.stream);
+      const int rcv = pl.kind == 2   ? launch_conv8n(p, kernel_dtype(dtype), d.k, rc.stream)
+                      : pl.kind == 3 ? launch_conv4n(p, kernel_dtype(dtype), d.k, rc.stream)
+                                     : launch_conv(p, kernel_dtype(dtype), pl.TN, rc.stream);
       prof_end(cat, tok, rc.stream);
       if (rcv) return 1;
     } else {
@@ -1090,6 +1098,9 @@ int nesti_model_cascade_stats(const nesti_model_t* m, nesti_cascade_stats_t* out
   out->tau = m->tau;
   memcpy(&out->sum_sq_pair_err, &h[4], 8);
   out->pairs = h[5];
+  out->widened = h[6];
+  out->widen_events = h[7];
+  out->tau_eff = std::max(m->tau, NESTI_GATE_WIDEN * out->max_margin_err);
   return 0;
 }
 
@@ -1358,12 +1369,14 @@ int nesti_model_macs(const nesti_model_t* m, int tower, int kind, double* nomina
     use += (double)parts * valid * d.cin * d.cout;
     // MFMA tiles the kernels issue: conv8n_kernel (8^3) and the remapped conv_igemm_kernel layout at 4^3 hold one x-line
     // (y, z) per 32-row tile and skip it when y + dy or z + dz leaves the volume; elsewhere every kept tap is issued in full
+    // (conv4n_kernel's tile is a single voxel: it issues exactly the taps that land inside the volume)
     double tap_sum = pl.n_taps;
     const int Si = 1 << d.log2S;
     if (pl.n_taps > 1 && (pl.kind >= 1 || (d.log2S == 2 && conv_remap(d.k, d.log2S, pl.n_taps)))) {
       tap_sum = 0;
       for (int t = 0; t < pl.n_taps; ++t)
-        tap_sum += (double)std::max(0, S - abs(pl.tap[t][0])) * std::max(0, S - abs(pl.tap[t][1])) / ((double)Si * Si);
+        tap_sum += (double)std::max(0, S - abs(pl.tap[t][0])) * std::max(0, S - abs(pl.tap[t][1])) / ((double)Si * Si) *
+                   (pl.kind == 3 ? (double)std::max(0, S - abs(pl.tap[t][2])) / Si : 1.0);
     }
     iss += (double)(1 << (3 * d.log2S)) * tap_sum * d.Cin_p * d.Cout_p;
   }

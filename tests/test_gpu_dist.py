@@ -70,6 +70,25 @@ def test_bench_two_ranks_debug_single_device(gpu_device):
     assert d["dtype"] == "f16x3c" and d["parity"]["meets_north_star"] and d["gate_cascade"]["rechecked"] > 0
 
 
+def test_bench_eight_ranks_debug_single_device(gpu_device):
+    """World size 8 -- the north star's node -- with real kernels: eight ranks on ONE GPU (gloo), each running its row blocks of
+    eight 4000-point clouds (500 rows of each: run_many's shared batches) and ONE all-gather per step; the line must carry
+    n_gpus 8, the strong-scaling leg (one cloud over eight ranks: 500 rows per rank) and a parity object that meets the north
+    star; every rank filters with the same gate margin."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+           "--points", "4000", "--batch", "1024", "--debug-single-device", "--no-cpu-baseline", "--no-secondary"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-6000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["points_per_cloud"] == 4000 and sum(d["config"]["routing_histogram"]) == 4000
+    assert d["strong"]["scaling"] == "strong" and d["strong"]["value"] > 0 and "ONE 4000-point cloud" in d["strong"]["workload"]
+    assert d["parity"]["queries"] == 500 and d["parity"]["meets_north_star"]
+    assert d["gate_cascade"]["tau_max_minus_min_over_ranks"] < 1e-4 * d["gate_cascade"]["tau"]
+    assert d["gate_cascade"]["queries"] == 4000 and d["gate_cascade"]["rechecked"] > 0       # rank 0's 8 x 500 rows
+
+
 def test_bench_strong_leg_at_one_gpu_equals_the_weak_figure(gpu_device):
     """--strong at N = 1: one cloud over one rank is the headline workload itself, so the two values must agree (VERDICT r02
     item 7; both legs time 2 steps of a 20k cloud, so a few per cent of noise is allowed)."""
