@@ -470,6 +470,16 @@ def main():
                                            "keeps a margin >= 1.5 x the largest error measured"}
         frac = hist / max(1, hist.sum())
         cal = not args.uncalibrated_gate
+        # the second half of BASELINE.json's metric: RMS angle error (unoriented, degrees; utils/evaluate.py:129-147) of the last
+        # cloud's normals against the analytic normals of its synthetic surface.  The weights are seeded random numbers (no
+        # checkpoint ships with the reference), so this is the error of an UNTRAINED network -- close to the 52 degrees of random
+        # directions -- and says nothing about Nesti-Net's accuracy; it is printed so that the line carries the metric's name and
+        # the evaluation code runs on the bench's own output
+        from nesti_net_amd.evaluate import shape_metrics
+        sm = shape_metrics(normals, clouds_np[-1][1])
+        res["rms_angle_error_deg"] = {"value": float(sm["rms"]), "pgp10": float(sm["pgp10"]), "oriented": float(sm["rms_o"]),
+                                      "against": "analytic normals of the synthetic surface, last cloud of the step",
+                                      "note": "synthetic (untrained) weights: not an accuracy figure of Nesti-Net"}
         if timing:
             res["roofline"] = roofline(roof_run, args.dtype, cfg, clouds_np, world, frac, cal)
             if roof_run is not main_run:

@@ -4,13 +4,13 @@
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 DT=${1:-f16x3c}
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/plt && rocprofv3 --kernel-trace --output-format csv -d /tmp/plt -- python3 $R/bench.py --dtype $DT --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-secondary --no-kernel-timing > /tmp/plt.json 2> /tmp/plt.err
+rm -rf /tmp/plt && rocprofv3 --kernel-trace --output-format csv -d /tmp/plt -- python3 $R/bench.py --streams 1 --dtype $DT --steps 1 --warmup 0 --no-cpu-baseline --no-parity --no-secondary --no-kernel-timing > /tmp/plt.json 2> /tmp/plt.err
 f=$(find /tmp/plt -name "*kernel_trace.csv" | head -1)
 python3 - "$f" > $O/per_launch_$DT.txt <<'P'
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-keep = [r for r in rows if re.search(r"conv8n?_kernel|conv_igemm_kernel|maxpool|mups", r["Kernel_Name"])]
+keep = [r for r in rows if re.search(r"conv8n_kernel|conv4n_kernel|conv_igemm_kernel|maxpool|mups", r["Kernel_Name"])]
 # the timed pass is the LAST 134 conv launches (+ pools); print everything after the last mups launch
 last_mups = max(i for i, r in enumerate(keep) if "mups" in r["Kernel_Name"])
 tot = {}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the gating tower's conv launches (last repetition) at batch $1; extra env as $2 (e.g. NESTI_CONV8N=0, or "" );
+# SQ counters of the gating tower's conv launches (last repetition) at batch $1; extra env as $2 (e.g. NESTI_LIB=<another build>, or "" );
 # dtype as $3 (f16 / f16x3 / bf16 ...)
 cd /tmp && export TMPDIR=/tmp
 B=${1:-2048}
@@ -24,7 +24,8 @@ n = len(ka) // 2
 for k, k2 in list(zip(ka, kb))[n:n + 18]:
     c, d = a[k], b[k2]
     wc = c["SQ_WAVE_CYCLES"]
-    busy = c["SQ_INSTS_MFMA"] * 32.0 / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)     # 32 cycles per 32x32x16 MFMA, 1024 SIMDs, GUI_ACTIVE summed over 8 XCDs
+    cyc = 16.0 if "conv4n" in k[1] else 32.0                                      # cycles per MFMA: 32x32x16 (32) or conv4n_kernel's 16x16x32 (16)
+    busy = c["SQ_INSTS_MFMA"] * cyc / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)      # 1024 SIMDs, GUI_ACTIVE summed over 8 XCDs
     print("%-34s wgs %5d | mfma %.3g (pipe busy %4.1f %%) valu %.3g salu %.3g lds %.3g | wave time: wait %.2f issue-stall %.2f active %.2f | lds conflict %.3f" % (
         k[1], k[2], c["SQ_INSTS_MFMA"], 100 * busy, c["SQ_INSTS_VALU"], c["SQ_INSTS_SALU"], c["SQ_INSTS_LDS"], c["SQ_WAIT_ANY"] / wc, c["SQ_WAIT_INST_ANY"] / wc, c["SQ_ACTIVE_INST_ANY"] / wc,
         d["SQ_LDS_BANK_CONFLICT"] / max(1, d["SQ_LDS_IDX_ACTIVE"])))

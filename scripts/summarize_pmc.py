@@ -16,7 +16,7 @@ DT = {"f32": "0", "bf16": "1", "f16": "2", "f16x3": "2", "f16x3c": "2", "bf16x3"
 
 
 def family(k):
-    m = re.search(r"(conv8n_kernel|conv8_kernel|conv_igemm_kernel|mups_kernel|maxpool2_kernel)<(\d)", k)
+    m = re.search(r"(conv8n_kernel|conv4n_kernel|conv_igemm_kernel|mups_kernel|maxpool2_kernel)<(\d)", k)
     if m:
         if m.group(2) != DT:
             return None
@@ -28,9 +28,12 @@ def family(k):
 
 def klass(k):
     """conv launches by kernel class and K loop: conv8 5^3 / 3^3, taps (igemm, several taps), 1x1 + FC (igemm, one tap)."""
-    m = re.search(r"conv8n?_kernel<(\d), (\d), (true|false)", k)
+    m = re.search(r"conv8n_kernel<(\d), (\d), (true|false)", k)
     if m:
         return "conv8_k%s%s" % (m.group(2), "_pair" if m.group(3) == "true" else "")
+    m = re.search(r"conv4n_kernel<(\d), (\d), (true|false)", k)
+    if m:
+        return "taps_4_2" + ("_pair" if m.group(3) == "true" else "")
     m = re.search(r"conv_igemm_kernel<(\d), \d+, (true|false), (true|false)", k)
     if m:
         return ("one_by_one_fc" if m.group(2) == "true" else "taps_4_2") + ("_pair" if m.group(3) == "true" else "")
@@ -56,8 +59,8 @@ def load(c):
 f, nf = load("FETCH_SIZE")
 w, nw = load("WRITE_SIZE")
 res = {"queries": queries, "dtype": dtype, "batch": batch, "calibrated_gate": True,
-       "command": "bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity --no-secondary under rocprofv3 --pmc (one pass over the cloud)",
-       "note": "FETCH_SIZE doubled per the gfx950 correction; units KiB -> bytes; 'conv' = conv8n_kernel + conv8_kernel + conv_igemm_kernel (f16x3c: includes the gate-margin calibration's 1024-query double pass, ~1 %)", "kernels": {}}
+       "command": "bench.py --streams 1 --steps 1 --warmup 0 --no-cpu-baseline --no-kernel-timing --no-parity --no-secondary under rocprofv3 --pmc (one pass over the cloud)",
+       "note": "FETCH_SIZE doubled per the gfx950 correction; units KiB -> bytes; 'conv' = conv8n_kernel + conv4n_kernel + conv_igemm_kernel (f16x3c: includes the gate-margin calibration's 1024-query double pass, ~1 %)", "kernels": {}}
 for k in sorted(set(f) | set(w)):
     rd, wr = 2.0 * f[k] * 1024, w[k] * 1024
     res["kernels"][k] = {"launches": nf[k], "hbm_read_bytes": rd, "hbm_write_bytes": wr,
