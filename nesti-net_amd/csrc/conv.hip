@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (a_off[j] >= 0)
-        glds16(in_b + a_off[j] + (X3 ? (long long)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (c & 1) * 64 : (long long)c * kRowBytes),
+        glds16(in_b + a_off[j] + (X3 ? (long long)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (c & 1) * 64 : (long long)c * p.in_chunk_bytes),
                lds0 + a_buf * kABytes + (wave * 8 + j) * 1024);
   };
   auto stage_b = [&](int c, int t, int b_buf) __attribute__((always_inline)) {

@@ -24,6 +24,8 @@ struct ConvParams {
   const int32_t* point_index;   // optional gather of INPUT points (routing); NULL -> identity
   int npoints;         // capacity (grid is sized for this)
   int in_cstride, in_coff;
+  int in_chunk_bytes;  // plain (non-pair) K loop of conv_igemm_kernel: byte distance between consecutive 128-byte K chunks of an
+                       // input row -- 128, or 256 when a plain-f16 layer reads the hi planes of a pair-layout tensor (model.hip)
   int out_cstride, out_coff;
   int n_chunks, n_taps;
   int tap_k;           // kernel edge k when all k^3 taps are present in x-fastest order (conv4n_kernel derives the taps from counters)

@@ -770,8 +770,8 @@ struct RunCtx {
   const int32_t* npoints_ptr;    // device-side live count or NULL
   const int32_t* point_index;    // gather for reads of bufs 0/1, or NULL
   hipStream_t stream;
-  bool fast = false;             // NESTI_F16X3C filter pass: this tower runs in plain f16 on rc.m->packed_fast; the MuPS tensor it
-                                 // reads keeps the model's pair layout and its first layer the pair K loop (pair_in below)
+  bool fast = false;             // NESTI_F16X3C filter pass: this tower runs in plain f16 on rc.m->packed_fast while the
+                                 // MuPS tensor it reads keeps the model's pair layout (only the hi plane is read)
 };
 
 int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* ws, size_t ws_bytes, float** out) {
@@ -786,11 +786,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
     const bool ext_in = op.in_buf < 1;
     if (op.kind == Op::CONV) {
       const LayerDesc& d = rc.m->graph.layers[op.layer];
-      // NESTI_F16X3C filter pass: the layer that reads the MuPS tensor (inception1's conv1|conv4) runs in the pair K loop on the
-      // pair-layout tensor with the model's pair weights and stores plain f16 -- it costs 5 ms per 100k queries more than the
-      // plain launch and removes the largest single contribution (~23 %) to the filter's error variance, i.e. rechecks
-      const bool pair_in = rc.fast && ext_in && x0_planes > 1;
-      const PackedLayer& pl = (rc.fast && !pair_in) ? rc.m->packed_fast[op.layer] : rc.m->packed[op.layer];
+      const PackedLayer& pl = rc.fast ? rc.m->packed_fast[op.layer] : rc.m->packed[op.layer];
       ConvParams p;
       memset(&p, 0, sizeof(p));
       p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf]; p.wpk = pl.wpk; p.bias = pl.bias;
@@ -802,6 +798,9 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.split = planes > 1 ? 1 : 0;
       const int in_planes = ext_in ? x0_planes : planes;
       p.in_cstride = (op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C) * in_planes; p.in_coff = op.in_coff * in_planes;
+      // distance between consecutive K chunks of a PLAIN kernel's input row: 128 B, except in the NESTI_F16X3C filter pass,
+      // whose plain-f16 first layer reads the hi plane of each 64-channel group [hi | lo] of the pair-layout MuPS tensor
+      p.in_chunk_bytes = kRowBytes * (planes == 1 ? in_planes : 1);
       p.out_cstride = T.bufs[op.out_buf].C * (op.out_f32 ? 1 : planes); p.out_coff = op.out_coff;
       p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.tap_k = d.k; p.log2S = d.log2S; p.s_real = d.s_real;
       p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0; p.acc_scale = pl.acc_scale; p.x3native = pl.x3n ? 1 : 0;
@@ -1068,8 +1067,8 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
   if (any_conv8 && conv8_selftest()) return 1;
   if (m->cascade) {
     m->packed_fast.resize(m->graph.layers.size());
-    for (const Op& op : m->graph.gate.ops)   // (the layer that reads the MuPS tensor keeps the pair weights: run_tower, pair_in)
-      if (op.kind == Op::CONV && op.in_buf >= 1 && pack_layer(m->graph.layers[op.layer], tt, NESTI_F16, &m->packed_fast[op.layer])) return 1;
+    for (const Op& op : m->graph.gate.ops)
+      if (op.kind == Op::CONV && pack_layer(m->graph.layers[op.layer], tt, NESTI_F16, &m->packed_fast[op.layer])) return 1;
     NESTI_CHECK_HIP(hipMalloc((void**)&m->cstat, 64));
     NESTI_CHECK_HIP(hipMemset(m->cstat, 0, 64));
   }
