@@ -46,13 +46,16 @@ constexpr int kThreads4 = 512;
 constexpr int kPts4 = 16;                    // points per workgroup
 constexpr int kTile4 = 1024;                 // 16 rows x 64 B
 constexpr int kBTap4 = 4 * kTile4;           // one tap's weights: 64 columns x 64 B
-constexpr int kSlotTaps4 = 5;                // taps per weight slot (capacity)
-constexpr int kSlot4 = kSlotTaps4 * kBTap4;  // 20 KiB
-constexpr int kNS4 = 3;
-constexpr int kAOff4 = kNS4 * kSlot4;        // 60 KiB
+constexpr int kABuf4 = 64 * kTile4;          // one input chunk: 64 voxel tiles = 64 KiB
 constexpr int kEpiStride4 = 144;             // bytes per row of the fp32 [1024][32] epilogue tile (+16 B pad)
-constexpr int kLds4 = 1024 * kEpiStride4;    // 144 KiB >= kAOff4 + 64 KiB
-static_assert(kLds4 >= kAOff4 + 64 * kTile4 && kLds4 <= 163840, "LDS budget");
+constexpr int kEpi4 = 1024 * kEpiStride4;    // 144 KiB
+// LDS of the instantiation for kernel edge K: two weight slots of one tap row each (K taps x 4 KiB), then the input chunk --
+// double-buffered where that fits 160 KiB (K <= 4: 32 + 128 KiB for K = 4), single otherwise (K = 5: 40 + 64 KiB)
+template <int K> constexpr bool dba4() { return 2 * K * kBTap4 + 2 * kABuf4 <= 163840; }
+template <int K> constexpr int lds4() {
+  constexpr int loop = 2 * K * kBTap4 + (dba4<K>() ? 2 : 1) * kABuf4;
+  return loop > kEpi4 ? loop : kEpi4;
+}
 constexpr unsigned kOob4 = 0x40000u;         // beyond any LDS allocation: ds_read returns 0
 
 typedef unsigned u32x4q_t __attribute__((ext_vector_type(4)));
@@ -93,7 +96,13 @@ __global__ __launch_bounds__(kThreads4) void conv4n_kernel(const ConvParams p) {
   // a row's source tiles are read one row ahead into a second register set where the registers allow it (hipcc spills the
   // other instantiations; without it the reads' latency is exposed once per row, behind the row barrier)
   constexpr bool PREF = !X3 && K == 4;
-  static_assert(K >= 2 && K <= kSlotTaps4, "slot capacity");
+  static_assert(K >= 2 && K <= 5, "kernel edge");
+  constexpr bool DBA = dba4<K>();            // the next chunk's input streams into a second buffer while this one is multiplied
+  constexpr int kSlotB = K * kBTap4;         // one weight slot = the K taps of one (dz, dy) row
+  constexpr int kAOff = 2 * kSlotB;
+  constexpr int APR = NR >= 6 ? 4 : 2;       // rows over which the next chunk's 8 staging instructions per wave are spread
+  constexpr int APP = 8 / APR;               // ... and how many of them a wave issues per row
+  static_assert(lds4<K>() <= 163840, "LDS budget");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,25 +129,27 @@ __global__ __launch_bounds__(kThreads4) void conv4n_kernel(const ConvParams p) {
   const bool st_ok = st_row < np_here;
   const size_t st_off = (size_t)st_row * 64 * p.in_cstride * kEsz +
                         (X3 ? (size_t)((st_slot & 1) * 16 + (st_slot >> 1) * (2 * kSplitGroup)) : (size_t)st_slot * 16);
-  auto stage_a = [&](int c) __attribute__((always_inline)) {
+  // tiles q0 .. q0 + nq - 1 of this wave's eight, chunk c, into input buffer `buf`
+  auto stage_a = [&](int c, int buf, int q0, int nq) __attribute__((always_inline)) {
     const size_t coff = X3 ? (size_t)(c >> 2) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 3) * 32 : (size_t)c * 64;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int s = wave * 8 + q;                                  // slot -> voxel: x = s & 3, line L = s >> 2 = 4 class + z
+    for (int qq = 0; qq < nq; ++qq) {
+      const int s = wave * 8 + q0 + qq;                            // slot -> voxel: x = s & 3, line L = s >> 2 = 4 class + z
       const int x = s & 3, z = (s >> 2) & 3, y = ((s >> 4) - z) & 3;
       const int v = 16 * z + 4 * y + x;
-      if (st_ok) glds16(in_b + (size_t)v * p.in_cstride * kEsz + coff + st_off, lds0 + kAOff4 + s * kTile4);
+      if (st_ok) glds16(in_b + (size_t)v * p.in_cstride * kEsz + coff + st_off, lds0 + kAOff + buf * kABuf4 + s * kTile4);
     }
   };
-  auto stage_b = [&](int c, int row, int slot) __attribute__((always_inline)) {   // the K taps of tap row `row` of chunk c
-    const unsigned char* src = w_tile + ((size_t)c * (K * K * K) + (size_t)row * K) * kBTap4;
-    for (int pid = wave; pid < 4 * K; pid += 8) glds16(src + pid * 1024 + lane * 16, lds0 + slot * kSlot4 + pid * 1024);
+  // tap row g of the layer's stream of rows (g = chunk * K^2 + row: the packed weights are contiguous in g) into weight slot g & 1
+  auto stage_b = [&](int g) __attribute__((always_inline)) {
+    const unsigned char* src = w_tile + (size_t)g * kSlotB;
+    for (int pid = wave; pid < 4 * K; pid += 8) glds16(src + pid * 1024 + lane * 16, lds0 + (g & 1) * kSlotB + pid * 1024);
   };
 
   // ---- per-lane fragment coordinates ------------------------------------------------------------------------------
   const int r16 = lane & 15, kb = lane >> 4;
   const unsigned frag = (unsigned)(r16 * 64 + ((kb ^ swz4(r16)) << 4));
-  const unsigned a_lane = lds0 + kAOff4 + frag;
+  const unsigned a_lane = lds0 + kAOff + frag;
   // weight fragments: plain = the lane's own K block; pair modes: set 0 reads W_hi for both halves of K ([W_hi ; W_hi]),
   // set 1 reads W_lo for the hi half and zeros (an out-of-range address) for the lo half
   unsigned b_lane[NB];
@@ -160,11 +171,11 @@ __global__ __launch_bounds__(kThreads4) void conv4n_kernel(const ConvParams p) {
       if ((unsigned)(z + d - 2) < 4u) zmk |= 1u << (2 * d + j);
     }
   // tap row (iz, iy) -> (live-line bits, per-lane LDS address of the row's first source tile: line 0, x' = 0)
-  auto row_info = [&](int iz, int iy, unsigned& live, unsigned& abase) __attribute__((always_inline)) {
+  auto row_info = [&](int iz, int iy, int buf, unsigned& live, unsigned& abase) __attribute__((always_inline)) {
     const int dz = iz - LO, dy = iy - LO;
     live = (zmk >> (2 * (dz + 2))) & (ymk >> (2 * (dy + 2))) & 3u;
     const int tile0 = 4 * (4 * ((cw + dy + dz) & 3) + 2 * h + dz);            // may be negative: only dead lines go out of range
-    abase = a_lane + (unsigned)(tile0 * kTile4);
+    abase = a_lane + (unsigned)(buf * kABuf4 + tile0 * kTile4);
   };
 
   f32x4 acc[2][4][4];                        // [line][x][column tile]
@@ -191,77 +202,92 @@ __global__ __launch_bounds__(kThreads4) void conv4n_kernel(const ConvParams p) {
       for (int s = 0; s < NB; ++s) dst[n][s] = lds128q(b_lane[s] + off + n * kTile4);
   };
 
-  for (int c = 0; c < p.n_chunks; ++c) {
-    __syncthreads();                         // every wave is done with the previous chunk
-    stage_a(c);
-    stage_b(c, 0, 0);
-    stage_b(c, 1, 1);
-    wait_vm0();
-    __syncthreads();
-    unsigned live_c, abase_c;
-    row_info(0, 0, live_c, abase_c);
-    load_b(b[K & 1], 0u);                    // tap u of a row uses b[u & 1]; an odd row leaves the next row's first set in b[1]
-    if (PREF) load_a(an, abase_c);
-    int iz = 0, iy = 0;                      // the row being multiplied
-    int slot = 0, fslot = 2;                 // weight slot of the current row; slot the next fill goes to
-    for (int row = 0; row < NR; ++row) {
-      if (row + 2 < NR) {
-        stage_b(c, row + 2, fslot);
-        fslot = fslot == kNS4 - 1 ? 0 : fslot + 1;
+  // The layer is ONE stream of G = n_chunks * K^2 tap rows.  Row g multiplies out of weight slot g & 1 and input buffer
+  // (chunk & 1); per row there is one barrier, at the top of its last tap: by then every wave holds that tap's weight fragments
+  // in registers, so the row's slot is free and the fill of row g + 2 is issued into it, and the fill of row g + 1 (issued a row
+  // earlier) is confirmed before the last tap prefetches row g + 1's first fragments.  The next chunk's input is staged into the
+  // other buffer during the first APR rows of a chunk, APP LDS-DMA instructions per wave and row, and confirmed a row later by
+  // the same counted s_waitcnt (LDS-DMA completes in order): no chunk boundary is ever waited for.
+  const int G = p.n_chunks * NR;
+  stage_a(0, 0, 0, 8);
+  stage_b(0);
+  stage_b(1);
+  wait_vm0();
+  __syncthreads();
+  unsigned live_c, abase_c;
+  row_info(0, 0, 0, live_c, abase_c);
+  load_b(b[K & 1], 0u);                      // tap u of a row uses b[u & 1]; an odd row leaves the next row's first set in b[1]
+  if (PREF) load_a(an, abase_c);
+  int c = 0, row = 0, iz = 0, iy = 0;        // chunk, row within the chunk and its (dz, dy) index
+  for (int g = 0; g < G; ++g) {
+    // the row after this one: next (dz, dy) of this chunk, or row 0 of the next chunk in the other input buffer
+    int cn = c, rown = row + 1, izn = iz, iyn = iy + 1;
+    if (iyn == K) { iyn = 0; ++izn; }
+    if (rown == NR) { rown = 0; izn = 0; iyn = 0; ++cn; }
+    unsigned live_n = 0u, abase_n = abase_c;
+    if (g + 1 < G) row_info(izn, iyn, DBA ? (cn & 1) : 0, live_n, abase_n);
+    const bool stage_now = DBA && row < APR && c + 1 < p.n_chunks;
+    if (stage_now) stage_a(c + 1, (c + 1) & 1, row * APP, APP);
+    if (!PREF) {
+      load_a(a, abase_c);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) a[j][x] = an[j][x];
+      load_a(an, abase_n);                   // (the last row re-reads its own tiles: harmless)
+    }
+    const unsigned lv = live_c;
+    const unsigned slot_off = (unsigned)((g & 1) * kSlotB), nslot_off = (unsigned)(((g + 1) & 1) * kSlotB);
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const bool last = (u == K - 1);
+      if ((K & 1) && u == 0) {               // moved to b[0] once per row
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int s = 0; s < NB; ++s) b[0][n][s] = b[1][n][s];
       }
-      const int nslot = slot == kNS4 - 1 ? 0 : slot + 1;
-      int izn = iz, iyn = iy + 1;
-      if (iyn == K) { iyn = 0; ++izn; }
-      unsigned live_n = 0u, abase_n = abase_c;
-      if (row + 1 < NR) row_info(izn, iyn, live_n, abase_n);
-      if (!PREF) {
-        load_a(a, abase_c);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int x = 0; x < 4; ++x) a[j][x] = an[j][x];
-        load_a(an, abase_n);                 // (the last row re-reads its own tiles: harmless)
-      }
-      const unsigned lv = live_c;
-#pragma unroll
-      for (int u = 0; u < K; ++u) {
-        const bool last = (u == K - 1);
-        if ((K & 1) && u == 0) {             // moved to b[0] once per row
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int s = 0; s < NB; ++s) b[0][n][s] = b[1][n][s];
+      uint4(&bc)[4][NB] = b[u & 1];
+      uint4(&bn)[4][NB] = b[(u + 1) & 1];
+      if (last) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the row's weight slot (and of its input tiles) are done
+        if (stage_now) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(APP) : "memory");   // row g + 1's weights have landed; the APP
+        else wait_vm0();                                                            // input pieces issued this row may still fly
+        __builtin_amdgcn_s_barrier();
+        if (g + 2 < G) stage_b(g + 2);
+        if (!DBA && rown == 0 && g + 1 < G) {
+          // single input buffer (K = 5): the chunk is dead once every wave has passed this barrier (its tiles were read at the
+          // row start); the next one is staged under this last tap's MFMAs and confirmed before the next row reads it
+          stage_a(cn, 0, 0, 8);
         }
-        uint4(&bc)[4][NB] = b[u & 1];
-        uint4(&bn)[4][NB] = b[(u + 1) & 1];
-        // fragment reads are unconditional (a dead line's reads land anywhere, its MFMAs are skipped): the number of reads in
-        // flight is static, so the compiler places exact s_waitcnt lgkmcnt(N)
-        load_b(bn, (unsigned)((last ? nslot : slot) * kSlot4 + (last ? 0 : (u + 1) * kBTap4)));
+      }
+      // fragment reads are unconditional (a dead line's reads land anywhere, its MFMAs are skipped): the number of reads in
+      // flight is static, so the compiler places exact s_waitcnt lgkmcnt(N)
+      load_b(bn, last ? nslot_off : slot_off + (unsigned)((u + 1) * kBTap4));
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (__builtin_expect((lv & (1u << j)) != 0, 1)) {
+      for (int j = 0; j < 2; ++j) {
+        if (__builtin_expect((lv & (1u << j)) != 0, 1)) {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              const int xs = x + u - LO;     // source voxel x' = x + dx: compile-time padding test
-              if (xs >= 0 && xs < 4) {
+          for (int x = 0; x < 4; ++x) {
+            const int xs = x + u - LO;       // source voxel x' = x + dx: compile-time padding test
+            if (xs >= 0 && xs < 4) {
 #pragma unroll
-                for (int s = 0; s < NB; ++s)
+              for (int s = 0; s < NB; ++s)
 #pragma unroll
-                  for (int n = 0; n < 4; ++n) mma16<DT>(acc[j][x][n], a[j][xs], bc[n][s]);
-              }
+                for (int n = 0; n < 4; ++n) mma16<DT>(acc[j][x][n], a[j][xs], bc[n][s]);
             }
           }
         }
       }
-      wait_vm0();                            // the fill issued at the top of this row has landed (this wave's pieces)
-      __builtin_amdgcn_s_barrier();          // ... everyone's; and nobody still reads the slot the next fill overwrites
-      slot = nslot;
-      live_c = live_n;
-      abase_c = abase_n;
-      iz = izn;
-      iy = iyn;
     }
+    if (!DBA && rown == 0 && g + 1 < G) {    // K = 5: the freshly staged chunk (and the fill issued with it) before anyone reads it
+      wait_vm0();
+      __builtin_amdgcn_s_barrier();
+    }
+    live_c = live_n;
+    abase_c = abase_n;
+    c = cn; row = rown; iz = izn; iy = iyn;
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);
   __syncthreads();                           // nobody still reads A / B: the LDS becomes the epilogue tile
@@ -345,12 +371,12 @@ int launch_conv4n_one(const ConvParams& p, hipStream_t stream) {
   NESTI_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
     NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4n_kernel<DT, K, X3>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLds4));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds4<K>()));
     if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
   }
   const int groups = (p.m_tiles + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * p.n_tiles)), block(kThreads4);
-  hipLaunchKernelGGL((conv4n_kernel<DT, K, X3>), grid, block, kLds4, stream, p);
+  hipLaunchKernelGGL((conv4n_kernel<DT, K, X3>), grid, block, lds4<K>(), stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -165,6 +165,36 @@ def test_ragged_batches_and_padding_rows(setup, net_f32, gpu_device):
     assert torch.equal(out[:5], full[:5])
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16", "f16x3"])
+def test_results_do_not_depend_on_the_point_group_a_query_lands_in(dtype, gpu_device):
+    """conv8n_kernel works on groups of 4 points and conv4n_kernel on groups of 16 (an MFMA tile there is one voxel of 16 points,
+    the last group of a launch is partly filled, routed experts see arbitrary counts): a query's outputs must be the same bits
+    whatever the batch size, its position in the batch and the number of queries routed to its expert -- sizes around the group
+    boundaries (1, 15, 16, 17, 33) against a 40-query batch, top-1 routed with a calibrated gate and evaluate-all."""
+    from nesti_net_amd import weights
+    from nesti_net_amd.calibrate import calibrate_gate
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    cfg = NestiConfig()
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid100k" in p][0])
+    g2 = load_golden_patches([p for p in golden_patch_files() if "ellipsoid20k" in p][0])
+    pts = np.concatenate([g["points"][:24], g2["points"][:16]])
+    n_eff = np.concatenate([g["n_eff"][:24], g2["n_eff"][:16]])
+    p, n = torch.as_tensor(pts, device=gpu_device), torch.as_tensor(n_eff, device=gpu_device)
+    W = calibrate_gate(cfg, weights.synthetic_weights(cfg), p, n, device=gpu_device)
+    net = NestiNet(cfg, W, dtype=dtype, device=gpu_device, max_batch=40)
+    full = [t.clone() for t in net(p, n)]
+    assert len(torch.unique(full[1])) >= 4                                # several experts, each with a ragged count
+    all7 = net.experts(net.mups(p, n), None).clone()                       # [E, 40, 3]
+    for size in (1, 15, 16, 17, 33):
+        for lo in (0, 40 - size):                                          # the same queries at other positions of other batches
+            out = net(p[lo:lo + size], n[lo:lo + size])
+            for a, b in zip(out, full):
+                assert torch.equal(a, b[lo:lo + size]), (dtype, size, lo)
+            sub = net.experts(net.mups(p[lo:lo + size], n[lo:lo + size]), None)
+            assert torch.equal(sub, all7[:, lo:lo + size]), (dtype, size, lo)
+
+
 def test_calibrated_gate_routes_to_many_experts_and_matches_oracle(setup, gpu_device):
     """Synthetic gate calibrated to spread its arg-max: the fused top-1 forward (gather by expert,
     per-expert towers with device-side counts, scatter) against the fp64 oracle on 48 queries."""
