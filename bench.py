@@ -73,14 +73,14 @@ def _cpu_model():
 def cpu_baseline(cfg, W, pts, routing_frac):
     """The oracle (numpy/scipy/torch-CPU restatement of the reference, kind "port") timed on this host on a bounded
     sample of the same workload: ball query on 2048 queries of the 100k cloud, MuPS on 64 and the CNN
-    on 384 of them.  The gate and each of the 7 experts are timed separately on all 384 queries, which gives both legs
+    on 256 of them.  The gate and each of the 7 experts are timed separately on all 256 queries, which gives both legs
     from one pass: ``value`` = gate + the experts weighted by this run's routing histogram -- the same top-1 work the GPU
     path does, so that GPU / CPU compares like with like -- and ``value_all7_experts`` = the reference's own
     evaluate-all-7-experts behaviour (test_n_est_w_experts.py:148) = gate + sum of the experts."""
     from oracle import mups_ref, net_ref, patches_ref
     cores = min(os.cpu_count() or 1, 32)      # torch-CPU conv3d stops scaling (and regresses) well before 256 threads
     torch.set_num_threads(cores)
-    n_patch, n_mups, n_net = 2048, 64, 384
+    n_patch, n_mups, n_net = 2048, 64, 256
     tree = patches_ref.build_tree(pts)
     _, r_abs = patches_ref.patch_radii(pts, cfg.patch_radius)
     t = time.time()
@@ -433,7 +433,7 @@ def main():
     legs = {}
     if headline and not args.no_secondary and world == 1:
         # the other modes on the same workload, a few steps each, each with its own parity object against the fp32 mode
-        for key, dt, st in (("fast_mode", "f16", 3), ("full_pair_mode", "f16x3", 2)) + ((("bf16_mode", "bf16", 3),) if args.bf16 else ()):
+        for key, dt, st in (("fast_mode", "f16", 3), ("full_pair_mode", "f16x3", 1)) + ((("bf16_mode", "bf16", 3),) if args.bf16 else ()):
             if dt != args.dtype:
                 legs[key] = (dt, st, timed_run(args, cfg, W, clouds_np, dt, st, 1, dev, world, rank, use_pg, timing,
                                                want_shard0=not args.no_parity))
