@@ -19,7 +19,10 @@
 //   * workgroup = 16 points x 64 voxels x 64 output columns; the K chunk is 64 bytes per row (32 x 16-bit or 16 x f32 channels),
 //     so the 16 points' chunk (64 KiB) stays resident in LDS for all k^3 taps; per row a wave reads 8 A + 4 k B fragments for up
 //     to 24 k MFMAs;
-//   * the weight tiles of a row of taps stream L2 -> LDS by LDS-DMA two rows ahead into 3 slots, one barrier per row.
+//   * the layer is ONE stream of n_chunks * k^2 tap rows: the weight tiles of a row stream L2 -> LDS by LDS-DMA into two slots
+//     (the fill of row g + 2 is issued at the row's only barrier, at the top of row g's last tap), and for k <= 4 the NEXT chunk's
+//     input streams into a second input buffer during the first rows of the current chunk, confirmed by counted s_waitcnt
+//     vmcnt -- no chunk boundary is waited for (timing-only bound for hiding the input staging: -6.4 / -6.9 %; got -4 / -5 %).
 //
 // Tile -> wave map.  Line (y, z) lives in LDS slots 4 L .. 4 L + 3 (x = 0 .. 3) with L = 4 ((y + z) & 3) + z: class
 // c = (y + z) & 3 holds one line of every y and of every z -- a Latin square -- so a tap row kills (nearly) the same number of
@@ -27,9 +30,10 @@
 // lines of tap row (dz, dy) are the slots 4 ((c + dy + dz) & 3) + 2 h + dz (+ 1): one wave-uniform base per row plus compile-time
 // offsets.
 //
-// LDS: [0, 60 KiB) three weight slots of up to five taps x 4 KiB, [60, 124 KiB) the input chunk; rows are 64 B with the 16-B slot
-// XOR-swizzled by {0, 2, 3, 1}[(row >> 2) & 3], applied on the DMA source address, which makes every ds_read_b128 lane group of
-// a 16-row fragment read conflict-free.  The epilogue reuses the LDS as an fp32 staging tile (two passes of 32 columns).
+// LDS: two weight slots of k taps x 4 KiB, then one (k = 5) or two (k <= 4: 32 + 128 KiB for k = 4) input buffers of 64 KiB; rows
+// are 64 B with the 16-B slot XOR-swizzled by {0, 2, 3, 1}[(row >> 2) & 3], applied on the DMA source address, which makes every
+// ds_read_b128 lane group of a 16-row fragment read conflict-free.  The epilogue reuses the LDS as an fp32 staging tile (two
+// passes of 32 columns).
 //
 // X3 (pair modes, model.hip: PackedLayer::x3n): the K chunk is 16 channels -- an LDS row holds [hi k0..15 | lo k0..15] and a
 // weight row [W_hi k0..15 | W_lo k0..15]; the K = 32 MFMA multiplies [hi | lo] x [W_hi ; W_hi] (= hi W_hi + lo W_hi) and
