@@ -8,6 +8,8 @@
    three activation planes [hi | lo | hi] against weights [W_hi ; W_hi ; W_lo] -- there each product has its own weight
    plane and can be switched off.  The two-plane layout of later commits only keeps the hi * W_lo switch (W_lo packed as
    zeros), so on those this script measures the weight-rounding share alone (":1" / ":2" suffixes are ignored).
+   Since round 4 the NESTI_X3_PLAIN hook only exists in builds made with -DNESTI_ATTRIBUTION (the product library has no such
+   switch): `make -C nesti-net_amd/csrc clean all EXTRA_CXXFLAGS=-DNESTI_ATTRIBUTION` (or a copy of the library via NESTI_LIB).
 3. Gate / experts time split in f16 and f16x3 on 32 768 queries.
 Prints JSON lines; -> gpurun_out/attr_sweep.txt"""
 import json
