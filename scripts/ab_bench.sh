@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B on ONE box: for each library variant under .ab/ (plus env overrides), run bench.py and print value/frac.
-# usage: scripts/ab_bench.sh "old.so" "new.so" "new.so:NESTI_CONV_REMAP=0" ...
+# usage: scripts/ab_bench.sh "old.so" "new.so" "new.so:SOME_ENV=0" ...
 for spec in "$@"; do
   lib=${spec%%:*}; envs=""; [[ "$spec" == *:* ]] && envs=${spec#*:}
   cp .ab/$lib nesti-net_amd/libnesti_hip.so

@@ -2,7 +2,7 @@
 avg-pool launches, the taps at 4^3 / 2^3, FC): each configuration "ENV=a,ENV2=b:dtype" runs in its own process (the
 library reads its switches once), B random MuPS rows, `reps` timed passes with the library's per-class hipEvents.
 
-    python scripts/ab_gate.py 32768 3 ":f16" "NESTI_CONV8_FLAGS=0:f16" "NESTI_X3_NATIVE=0:f16x3" ":f16x3"
+    python scripts/ab_gate.py 32768 3 "NESTI_LIB=/root/repo/.ab/libnesti_old.so:f16" ":f16" "NESTI_LIB=/root/repo/.ab/libnesti_old.so:f16x3" ":f16x3"
 -> one line per configuration and repetition round (two rounds, interleaved), also appended to gpurun_out/ab_gate.txt"""
 import json
 import os

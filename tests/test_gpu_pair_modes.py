@@ -119,7 +119,7 @@ def test_pair_mode_agrees_with_the_fp32_mode_on_every_graph(name, mode, gpu_devi
 @pytest.mark.parametrize("mode", MODES)
 def test_pair_mode_limits_two_channel_groups_and_ragged_batches(mode, gpu_device):
     """NESTI_MAX_SCALES = 4: 80 MuPS channels = two 64-channel groups of planes; a batch that is not a multiple of the
-    four points conv8_kernel handles per workgroup; rows with n_eff = 0 are skipped, not computed."""
+    four points conv8n_kernel (or the sixteen conv4n_kernel) handles per workgroup; rows with n_eff = 0 are skipped, not computed."""
     from nesti_net_amd import weights
     from nesti_net_amd.config import NestiConfig
     from nesti_net_amd.model import NestiNet
