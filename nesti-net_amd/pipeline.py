@@ -23,7 +23,7 @@ class NormalEstimator:
         self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
         # subsample='reference': balls larger than P are thinned exactly like the reference does (scipy cKDTree traversal
         # order + ONE numpy RandomState stream over all patches in visiting order, utils/pcpnet_dataset.py:304-321), on the
-        # host, ~1 ms per patch -- for diffing against a real reference run row by row (refsample.py).  The default 'hash'
+        # host, ~0.5 ms per patch -- for diffing against a real reference run row by row (refsample.py).  The default 'hash'
         # is the GPU ball query with its order-independent uniform subset.
         if subsample not in ("hash", "reference"):
             raise ValueError("subsample must be 'hash' or 'reference'")
