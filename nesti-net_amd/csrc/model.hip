@@ -975,7 +975,7 @@ using namespace nesti;
 extern "C" {
 
 const char* nesti_last_error(void) { return g_error.c_str(); }
-const char* nesti_version(void) { return "nesti-hip 0.3 (gfx950)"; }
+const char* nesti_version(void) { return "nesti-hip 0.4 (gfx950)"; }
 
 void nesti_default_config(nesti_config_t* cfg) {
   memset(cfg, 0, sizeof(*cfg));
