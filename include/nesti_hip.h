@@ -158,9 +158,13 @@ void nesti_model_destroy(nesti_model_t* m);
  * The margin protects itself: a forward call filters with
  *     tau_eff = max(tau, NESTI_GATE_WIDEN x max_margin_err measured since the last reset)
  * and, after its own recheck rounds, re-decides the rows whose f16 margin lies between that threshold and NESTI_GATE_WIDEN x
- * the (possibly larger) error it has just measured -- a second, normally empty round on the device, no host
- * synchronisation.  A row keeps the f16 arg-max only while its margin is at least NESTI_GATE_WIDEN x the largest error the
- * f16 gate has shown on any row decided twice.
+ * the (possibly larger) error it has just measured -- up to NESTI_GATE_WIDEN_PASSES further, normally empty passes on the
+ * device (each takes a snapshot of the largest error when it starts and covers the band up to NESTI_GATE_WIDEN x that, so an
+ * error first seen inside a widening pass is covered by the next pass of the same call), no host synchronisation.  A row
+ * keeps the f16 arg-max only while its margin is at least NESTI_GATE_WIDEN x the largest error the f16 gate has shown on any
+ * row decided twice up to the start of the call's last widening pass.  The guarantee is per call: calls in flight on other
+ * streams share the counters, and what they measure after this call's last snapshot protects this stream from its next
+ * call on.
  * nesti_model_cascade_stats synchronises `stream`, copies the counters accumulated by every forward call since the last
  * reset and optionally resets them:
  *   queries        rows that went through the gate,
@@ -171,9 +175,10 @@ void nesti_model_destroy(nesti_model_t* m);
  *   sum_sq_pair_err / pairs: the same errors squared and summed over all (rechecked row, k != a) pairs, and their count:
  *                  sqrt(sum / pairs) is the standard deviation sigma of the f16 pass's error on one logit difference (the
  *                  errors are rounding noise: zero-mean, independent of the margin); tau is chosen as a multiple of it,
- *   widened        rows re-decided by a widening round, widen_events: forward calls whose widening round was not empty,
+ *   widened        rows re-decided by a widening pass, widen_events: widening passes that were not empty,
  *   tau_eff        the threshold the next forward call starts from. */
 #define NESTI_GATE_WIDEN 1.5f
+#define NESTI_GATE_WIDEN_PASSES 3
 typedef struct {
   uint64_t queries, rechecked, changed;
   float max_margin_err;
@@ -185,6 +190,19 @@ typedef struct {
 } nesti_cascade_stats_t;
 int nesti_model_set_gate_margin(nesti_model_t* m, float tau);
 int nesti_model_cascade_stats(const nesti_model_t* m, nesti_cascade_stats_t* out, int reset, void* stream);
+/* Multi-GPU (no reference counterpart): every rank should filter with the largest error ANY rank has
+ * measured.  _export writes this model's max_margin_err to dst_dev[0]; _import raises it to the largest finite value of
+ * src_dev[0..n).  Both are one tiny kernel on `stream`, no host synchronisation: the value rides in a spare row of the
+ * per-step all-gather (nesti-net_amd/dist.py) instead of a collective of its own. */
+int nesti_model_gate_error_export(const nesti_model_t* m, float* dst_dev, void* stream);
+int nesti_model_gate_error_import(nesti_model_t* m, const float* src_dev, int n, void* stream);
+
+/* EXPERIMENT (pair-mode experts_n_est models, 8^3 grid; no reference counterpart): which of the experts' k^3 tap layers run ONE
+ * 16-bit product (hi * W_hi, reading only the hi planes of their pair-layout input, writing pairs again) instead of three.
+ * Bits: 0 / 1 = inception1 conv2 (3^3) / conv3 (5^3), 2 / 3 = inception2 conv2 / conv3, 4 / 5 = inception4 conv2 (2^3) / conv3 (4^3).
+ * 0 (the default) is NESTI_F16X3 proper.  Any other value does NOT hold the 1e-5 cosine tolerance on every query
+ * (profiles/r05_expert_mix.txt); it exists to measure that.  Must not be changed while forward calls are in flight. */
+int nesti_model_set_expert_mix(nesti_model_t* m, int mask);
 
 /* Workspace of ONE tower for `batch` queries, from the configuration alone (no device needed): tower = -1 the gating
  * net, 0..E-1 an expert.  dtype as nesti_model_create (NESTI_F16X3C: the gate figure is the f16 filter's). */
@@ -287,9 +305,10 @@ uint32_t nesti_crc32c(const void* data, size_t n, uint32_t crc);
  * Categories are kernels (the four conv categories are the layer classes of DESIGN.md 4.3 / 4.4); phases say which part
  * of the forward pass launched them (NESTI_F16X3C: the gate's f16 filter pass counts as GATE, its f16x3 pass as RECHECK).
  * Not thread-safe; leave it off outside measurements. */
-enum { NESTI_PROF_CONV8_K5 = 0,   /* conv8_kernel, 5^3 taps at 8^3                                  */
-       NESTI_PROF_CONV8_K3 = 1,   /* conv8_kernel, 3^3 taps at 8^3                                  */
-       NESTI_PROF_TAPS = 2,       /* conv_igemm_kernel, k^3 taps at 4^3 / 2^3 (and 3^3-in-4^3)      */
+enum { NESTI_PROF_CONV8_K5 = 0,   /* conv8n_kernel, 5^3 taps at 8^3                                 */
+       NESTI_PROF_CONV8_K3 = 1,   /* conv8n_kernel, 3^3 taps at 8^3                                 */
+       NESTI_PROF_TAPS = 2,       /* conv4n_kernel: k^3 taps at 4^3; conv_igemm_kernel: taps at 2^3
+                                   * and on the 3^3 grid embedded in 4^3                            */
        NESTI_PROF_ONE_BY_ONE = 3, /* conv_igemm_kernel, 1x1x1 layers (+ fused avg-pool) and FC      */
        NESTI_PROF_MUPS = 4, NESTI_PROF_POOL = 5, NESTI_PROF_PATCHES = 6, NESTI_PROF_CATEGORIES = 7 };
 enum { NESTI_PHASE_INPUT = 0,     /* search grid, ball query, MuPS                                  */

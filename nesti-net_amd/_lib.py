@@ -35,6 +35,7 @@ class CCascadeStats(ctypes.Structure):
 
 
 GATE_WIDEN = 1.5      # NESTI_GATE_WIDEN (include/nesti_hip.h)
+GATE_WIDEN_PASSES = 3  # NESTI_GATE_WIDEN_PASSES
 
 
 class NestiError(RuntimeError):
@@ -62,6 +63,9 @@ SIGNATURES = {
     "nesti_model_destroy": (None, [_vp]),
     "nesti_model_set_gate_margin": (_i, [_vp, ctypes.c_float]),
     "nesti_model_cascade_stats": (_i, [_vp, ctypes.POINTER(CCascadeStats), _i, _vp]),
+    "nesti_model_gate_error_export": (_i, [_vp, _vp, _vp]),
+    "nesti_model_gate_error_import": (_i, [_vp, _vp, _i, _vp]),
+    "nesti_model_set_expert_mix": (_i, [_vp, _i]),
     "nesti_tower_workspace_bytes": (_sz, [_cfgp, _i, _i, _i]),
     "nesti_workspace_bytes": (_sz, [_vp, _i]),
     "nesti_model_mups_cstride": (_i, [_vp]),

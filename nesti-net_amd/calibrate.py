@@ -68,6 +68,7 @@ def calibrate_gate_margin(net, points, n_eff, sigmas=GATE_MARGIN_SIGMAS, over_ma
     A sample of fewer than ``GATE_MARGIN_MIN_QUERIES`` queries cannot carry a 7-sigma statement: the margin is then left at
     infinity, which makes the mode plain f16x3 (always safe, no filter gain)."""
     if int(points.shape[0]) < GATE_MARGIN_MIN_QUERIES:
+        net.cascade_stats(reset=True)         # the counters start from zero for this shape here too (ADVICE r04)
         net.set_gate_margin(1e30)
         return float("inf")
     net.cascade_stats(reset=True)

@@ -8,6 +8,7 @@ The trained-model directory holds either ``model.nstw`` (variables + hyper-param
 :mod:`.tf_ckpt` without TensorFlow); ``--synthetic_weights`` substitutes seeded random weights (no
 checkpoint ships with the reference)."""
 import argparse
+import ctypes
 import os
 import sys
 
@@ -46,9 +47,35 @@ def build_parser():
     p.add_argument("--subsample", default="hash", choices=["hash", "reference"],
                    help="how balls with more than num_point points are thinned: hash = on the GPU, order-independent (default); "
                         "reference = exactly like the reference (scipy cKDTree order + its RandomState stream, on the host, "
-                        "~1 ms per patch) for row-by-row diffs against a real reference run")
+                        "a fraction of a millisecond per patch: nesti-net_amd/refsample.py) for row-by-row diffs against a real "
+                        "reference run")
     p.add_argument("--synthetic_weights", action="store_true", help="use seeded synthetic weights if model.nstw is absent")
     return p
+
+
+def fit_batch(cfg, dtype, batch, device, lanes=2, reserve=2 << 30):
+    """The largest batch <= ``batch`` (halving, 256-row granularity, >= 256) whose ``lanes`` arenas fit the device's free
+    memory with ``reserve`` bytes to spare.  Sized from the configuration alone (nesti_tower_workspace_bytes: the gate
+    tower dominates an arena; + the MuPS tensor and the per-query bookkeeping), before any model exists."""
+    from . import _lib
+    from .config import DTYPES
+    lib = _lib.load()
+    free = torch.cuda.mem_get_info(device)[0] - reserve
+    c = cfg.to_c()
+    pair = dtype in ("f16x3", "bf16x3", "f16x3c")
+    x0_per_q = 512 * 64 * (4 if (pair or dtype == "f32") else 2)          # MuPS rows of one query in the model's layout
+    while batch > 256:
+        ecap = batch if batch <= 8192 else (batch + 3) // 4 + 256      # csrc/model.hip: expert_cap / cascade_cap
+        ccap = batch if batch <= 4096 else (batch + 3) // 4 + 256
+        towers = [lib.nesti_tower_workspace_bytes(ctypes.byref(c), DTYPES[dtype], t, batch if t < 0 else ecap)
+                  for t in range(-1, max(1, cfg.n_towers))]
+        if dtype == "f16x3c":                  # the recheck rounds run the f16x3 gate on a quarter of a large batch
+            towers.append(lib.nesti_tower_workspace_bytes(ctypes.byref(c), DTYPES["f16x3"], -1, ccap))
+        arena = max(towers) + batch * (x0_per_q + 160)
+        if lanes * arena <= free:
+            break
+        batch = max(256, (batch // 2 + 255) // 256 * 256)
+    return batch
 
 
 def main(argv=None):
@@ -99,6 +126,12 @@ def main(argv=None):
     lib_batch = FLAGS.lib_batch or {"f16x3c": 50000, "f16": 50000, "bf16": 50000, "f32": 8192}.get(dtype, 25000)
     half = (max(dataset.shape_patch_count + [1]) + 1) // 2
     batch = max(FLAGS.batch_size, min(lib_batch, max(1024, (half + 255) // 256 * 256)))
+    # ... and what the device has free right now: two arenas (one per stream) + the 1024-query calibration workspace must fit
+    # (the defaults are sized for an otherwise idle 288 GB MI355X; a shared or smaller device gets smaller batches, not an OOM)
+    fit = fit_batch(cfg, dtype, batch, device, lanes=2)
+    if fit != batch:
+        printout("library batch %d -> %d rows: %.1f GB free on %s" % (batch, fit, torch.cuda.mem_get_info(device)[0] / 1e9, device))
+        batch = fit
     est = NormalEstimator(cfg, W, dtype=dtype, device=device, batch=batch, n_streams=2, subsample=FLAGS.subsample)
     printout("Model restored.")
 

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(kThreads4) void conv4n_kernel(const ConvParams p) {
                         (X3 ? (size_t)((st_slot & 1) * 16 + (st_slot >> 1) * (2 * kSplitGroup)) : (size_t)st_slot * 16);
   // tiles q0 .. q0 + nq - 1 of this wave's eight, chunk c, into input buffer `buf`
   auto stage_a = [&](int c, int buf, int q0, int nq) __attribute__((always_inline)) {
-    const size_t coff = X3 ? (size_t)(c >> 2) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 3) * 32 : (size_t)c * 64;
+    const size_t coff = X3 ? (size_t)(c >> 2) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 3) * 32
+                           : p.in_pair ? (size_t)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 1) * 64 : (size_t)c * 64;
 #pragma unroll
     for (int qq = 0; qq < nq; ++qq) {
       const int s = wave * 8 + q0 + qq;                            // slot -> voxel: x = s & 3, line L = s >> 2 = 4 class + z

@@ -132,7 +132,8 @@ __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
     for (int jz = 0; jz < NZ; ++jz) {
       const int zp = zlo + jz, yp = (wave - zp) & 7;     // source tile (y', z') of this wave's run: (y' + z') & 7 == wave
       const unsigned char* src = in_b + (size_t)((zp * 64 + yp * 8) * p.in_cstride) * kEsz +
-                                 (X3 ? (size_t)(c >> 2) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 3) * 32 : (size_t)c * 64);
+                                 (X3 ? (size_t)(c >> 2) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 3) * 32
+                                     : p.in_pair ? (size_t)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 1) * 64 : (size_t)c * 64);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         if (a_ok[h]) glds16(src + a_voff[h], lds0 + kAOffN + (wave * NZ + jz) * kTileN + h * 1024);

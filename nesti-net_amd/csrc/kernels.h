@@ -26,6 +26,9 @@ struct ConvParams {
   int in_cstride, in_coff;
   int in_chunk_bytes;  // plain (non-pair) K loop of conv_igemm_kernel: byte distance between consecutive 128-byte K chunks of an
                        // input row -- 128, or 256 when a plain-f16 layer reads the hi planes of a pair-layout tensor (model.hip)
+  int in_pair;         // plain K loop of conv8n_kernel / conv4n_kernel: 1 = the input tensor has the pair layout and only its hi planes
+                       // are read (64-byte chunk c = 32 channels sits at byte (c >> 1) * 256 + (c & 1) * 64 of a row); with
+                       // `split` the outputs are written as pairs again -- a single-product layer inside a pair-mode tower
   int out_cstride, out_coff;
   int n_chunks, n_taps;
   int tap_k;           // kernel edge k when all k^3 taps are present in x-fastest order (conv4n_kernel derives the taps from counters)
@@ -99,19 +102,25 @@ int launch_gate_finish(const float* logits, int lstride, int B, int E, float* pr
 // NESTI_F16X3C, the two-stage gate (pool.hip): keep [B, NESTI_MAX_EXPERTS] f32 (the f16 pass's logits), flag_list [B],
 // cstat = the model's device counters, fcounts = a 512-byte block of the call's workspace laid out as int32 words:
 //   [0] rows flagged by the filter pass, [kRoundCountsOff + r] of them in recheck round r (cap rows per round),
-//   [kTauEffOff] the call's threshold tau_eff as a float, [kWidenCountOff] rows flagged by the widening round,
-//   [kWidenRoundsOff + r] of them in widening round r
+//   [kTauEffOff] the call's threshold tau_eff as a float (raised to the upper end of every band a widening pass has covered),
+//   [kWidenUpperOff] the upper end of the current widening pass's band (float, snapshotted when the pass starts),
+//   [kWidenCountOff] rows flagged by the current widening pass, [kWidenRoundsOff + r] of them in its tower round r
 constexpr int kMaxCascadeRounds = 24;
-constexpr int kRoundCountsOff = 8, kTauEffOff = 40, kWidenCountOff = 48, kWidenRoundsOff = 56;
+constexpr int kRoundCountsOff = 8, kTauEffOff = 40, kWidenUpperOff = 41, kWidenCountOff = 48, kWidenRoundsOff = 56;
 static_assert(kRoundCountsOff + kMaxCascadeRounds <= kTauEffOff && kWidenRoundsOff + kMaxCascadeRounds <= 128, "fcounts layout");
 int launch_gate_flag(const float* logits, int lstride, int B, int E, float tau, float widen, float* probs, int32_t* expert,
                      float* keep, int32_t* fcounts, int32_t* flag_list, int cap, int n_rounds, unsigned long long* cstat,
                      hipStream_t stream);
-// after the recheck rounds: the flag list (storage reused) of the rows in [tau_eff, widen * max_margin_err) and its round counts
+// after the recheck rounds, one widening pass: snapshot upper = widen * max_margin_err, flag list (storage reused) of the rows
+// in [tau_eff, upper), its round counts, then tau_eff = max(tau_eff, upper)
 int launch_gate_widen(const float* keep, int B, int E, float widen, int32_t* fcounts, int32_t* flag_list, int cap, int n_rounds,
                       unsigned long long* cstat, hipStream_t stream);
 int launch_gate_recheck(const float* logits, int lstride, const int32_t* flag_list, const int32_t* count_ptr, int cap, int E,
                         const float* keep, float* probs, int32_t* expert, unsigned long long* cstat, hipStream_t stream);
+// max_margin_err of the model's counters <-> a device float (multi-GPU: every rank filters with the largest error any rank
+// has measured, nesti_model_gate_error_export / _import)
+int launch_gate_error_export(const unsigned long long* cstat, float* dst, hipStream_t stream);
+int launch_gate_error_import(unsigned long long* cstat, const float* src, int n, hipStream_t stream);
 // out[i * n_rounds + r] = clamp(counts[i] - r * cap, 0, cap): the rows of list i that round r of a `cap`-row tower covers
 int launch_round_counts(const int32_t* counts, int n_lists, int cap, int n_rounds, int32_t* out, hipStream_t stream);
 // ms_sw_n_est's switch (models/ms_sw_n_est.py:80-82): noise = logits[b*lstride]; expert = noise < threshold ? 0 : 1;

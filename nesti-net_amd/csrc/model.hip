@@ -425,6 +425,7 @@ struct PackedLayer {
   int kind = 0;              // 0: conv_igemm_kernel (conv.hip), 2: conv8n_kernel (conv8n.hip: 4 points x a z half x 64 columns
                              // per workgroup), 3: conv4n_kernel (conv4n.hip: 16 points x 64 voxels x 64 columns)
   bool x3n = false;          // pair modes: K chunks [hi | lo] / [W_hi | W_lo], three MFMAs per fragment set
+  int mix_bit = -1;          // packed_mix entries: which bit of nesti_model::expert_mix switches this layer to the single-product loop
   float acc_scale = 1.0f;    // 2^-s when the packed weights carry a 2^s scale (NESTI_F16X3)
   int8_t tap[kMaxTaps][4];
 };
@@ -440,10 +441,15 @@ struct nesti_model {
   // margin and the device counters of the two-stage gate (include/nesti_hip.h: nesti_cascade_stats_t)
   bool cascade = false;
   std::vector<nesti::PackedLayer> packed_fast;
+  // pair modes, EXPERIMENT (nesti_model_set_expert_mix): the experts' k^3 tap layers at 8^3 / 4^3 once more
+  // in plain f16 -- a layer whose bit is set in expert_mix reads the hi planes of its pair-layout input, multiplies ONE product
+  // and writes its outputs as pairs again
+  std::vector<nesti::PackedLayer> packed_mix;
+  int expert_mix = 0;
   float tau = 0.25f;
   unsigned long long* cstat = nullptr;
   ~nesti_model() {
-    for (auto* v : {&packed, &packed_fast})
+    for (auto* v : {&packed, &packed_fast, &packed_mix})
       for (auto& p : *v) {
         if (p.wpk) (void)hipFree(p.wpk);
         if (p.bias) (void)hipFree(p.bias);
@@ -772,6 +778,7 @@ struct RunCtx {
   hipStream_t stream;
   bool fast = false;             // NESTI_F16X3C filter pass: this tower runs in plain f16 on rc.m->packed_fast while the
                                  // MuPS tensor it reads keeps the model's pair layout (only the hi plane is read)
+  int mix = 0;                   // expert towers in a pair mode: the layers whose packed_mix bit is set here run single-product
 };
 
 int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* ws, size_t ws_bytes, float** out) {
@@ -786,9 +793,12 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
     const bool ext_in = op.in_buf < 1;
     if (op.kind == Op::CONV) {
       const LayerDesc& d = rc.m->graph.layers[op.layer];
-      const PackedLayer& pl = rc.fast ? rc.m->packed_fast[op.layer] : rc.m->packed[op.layer];
+      const bool mixl = !rc.fast && rc.mix && op.layer < (int)rc.m->packed_mix.size() && rc.m->packed_mix[op.layer].wpk &&
+                        ((rc.mix >> rc.m->packed_mix[op.layer].mix_bit) & 1);
+      const PackedLayer& pl = rc.fast ? rc.m->packed_fast[op.layer] : mixl ? rc.m->packed_mix[op.layer] : rc.m->packed[op.layer];
       ConvParams p;
       memset(&p, 0, sizeof(p));
+      p.in_pair = mixl ? 1 : 0;
       p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf]; p.wpk = pl.wpk; p.bias = pl.bias;
       p.npoints_ptr = rc.npoints_ptr; p.point_index = ext_in ? rc.point_index : nullptr;
       p.npoints = rc.NB;
@@ -812,6 +822,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
       const int cat = conv_category(d, pl);
       const int tok = prof_begin(cat, rc.stream);
+      // (a mixed layer is a plain f16 / bf16 kernel inside a pair-mode tower: kernel_dtype is the same element type either way)
       const int rcv = pl.kind == 2   ? launch_conv8n(p, kernel_dtype(dtype), d.k, rc.stream)
                       : pl.kind == 3 ? launch_conv4n(p, kernel_dtype(dtype), d.k, rc.stream)
                                      : launch_conv(p, kernel_dtype(dtype), pl.TN, rc.stream);
@@ -904,11 +915,12 @@ int gate_cascade(const nesti_model* m, const void* X0, int B, unsigned char* ws,
   if (launch_gate_flag(logits, lstride, B, E, m->tau, NESTI_GATE_WIDEN, probs, expert, keep, fcounts, flag_list, cap, rounds,
                        m->cstat, stream))
     return 1;
-  // pass 0: the rows below the call's threshold; pass 1: the widening round -- the band between that threshold and
-  // NESTI_GATE_WIDEN x the largest error measured so far, pass 0's rows included (normally empty: its launches find a zero
-  // row count on the device and return; no host synchronisation, so the whole call stays graph-capturable)
-  for (int pass = 0; pass < 2; ++pass) {
-    if (pass == 1 && launch_gate_widen(keep, B, E, NESTI_GATE_WIDEN, fcounts, flag_list, cap, rounds, m->cstat, stream)) return 1;
+  // pass 0: the rows below the call's threshold; passes 1 .. NESTI_GATE_WIDEN_PASSES: widening passes -- the band between the
+  // threshold reached so far and NESTI_GATE_WIDEN x the largest error measured up to the start of the pass, so an error first
+  // seen inside a widening pass is covered by the next one of the SAME call (normally every pass is empty: its launches find a
+  // zero row count on the device and return; no host synchronisation, so the whole call stays graph-capturable)
+  for (int pass = 0; pass <= NESTI_GATE_WIDEN_PASSES; ++pass) {
+    if (pass >= 1 && launch_gate_widen(keep, B, E, NESTI_GATE_WIDEN, fcounts, flag_list, cap, rounds, m->cstat, stream)) return 1;
     const int32_t* round_counts = fcounts + (pass == 0 ? kRoundCountsOff : kWidenRoundsOff);
     for (int r = 0; r < rounds; ++r) {
       RunCtx exact{m, cap, round_counts + r, flag_list + (size_t)r * cap, stream};
@@ -950,12 +962,12 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
       if (counts) {   // top-1 routing: only the points whose arg-max is e (test_n_est_w_experts.py:150-152), `cap` of them per round
         const int32_t* list = lists + (size_t)e * B + (size_t)r * cap;
         const int32_t* cnt = ecounts + e * rounds + r;
-        RunCtx rc{m, cap, cnt, list, stream};
+        RunCtx rc{m, cap, cnt, list, stream, false, m->expert_mix};
         if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
         if (launch_scatter3(out, ostride, list, cnt, cap, normals, stream)) return 1;
       } else {        // reference behaviour: every expert on every point -> [E,B,3], rows [r * cap, ...) of the batch per round
         const int take = std::min(cap, B - r * cap);
-        RunCtx rc{m, take, nullptr, nullptr, stream};
+        RunCtx rc{m, take, nullptr, nullptr, stream, false, m->expert_mix};
         if (run_tower(rc, T, (const unsigned char*)X0 + (size_t)r * cap * x0_row, tower_ws, tower_bytes_, &out)) return 1;
         if (launch_scatter3(out, ostride, nullptr, nullptr, take, normals + ((size_t)e * B + (size_t)r * cap) * 3, stream)) return 1;
       }
@@ -975,7 +987,7 @@ using namespace nesti;
 extern "C" {
 
 const char* nesti_last_error(void) { return g_error.c_str(); }
-const char* nesti_version(void) { return "nesti-hip 0.4 (gfx950)"; }
+const char* nesti_version(void) { return "nesti-hip 0.5 (gfx950)"; }
 
 void nesti_default_config(nesti_config_t* cfg) {
   memset(cfg, 0, sizeof(*cfg));
@@ -1065,6 +1077,22 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
   bool any_conv8 = false;
   for (const PackedLayer& pl : m->packed) any_conv8 = any_conv8 || pl.kind == 2;
   if (any_conv8 && conv8_selftest()) return 1;
+  if (act_planes(dtype) > 1 && cfg->arch == NESTI_ARCH_EXPERTS && cfg->grid_n == 8) {
+    m->packed_mix.resize(m->graph.layers.size());
+    const int plain = kernel_dtype(dtype);
+    for (const Tower& T : m->graph.experts)
+      for (const Op& op : T.ops) {
+        if (op.kind != Op::CONV) continue;
+        const LayerDesc& d = m->graph.layers[op.layer];
+        if (!use_conv8(d) && !(use_conv4(d, plain) && m->packed[op.layer].kind == 3)) continue;
+        // "inception<B>Expert_<i>_conv<2|3>": blocks 1, 2 (8^3) and 4 (4^3); conv2 is the smaller kernel of the block
+        const int blk = d.scope.size() > 9 ? d.scope[9] - '0' : 0;
+        const int idx = blk == 1 ? 0 : blk == 2 ? 1 : blk == 4 ? 2 : -1;
+        if (idx < 0) continue;
+        if (pack_layer(d, tt, plain, &m->packed_mix[op.layer])) return 1;
+        m->packed_mix[op.layer].mix_bit = 2 * idx + (d.scope.back() == '3' ? 1 : 0);
+      }
+  }
   if (m->cascade) {
     m->packed_fast.resize(m->graph.layers.size());
     for (const Op& op : m->graph.gate.ops)
@@ -1086,6 +1114,14 @@ int nesti_model_set_gate_margin(nesti_model_t* m, float tau) {
   return 0;
 }
 
+int nesti_model_set_expert_mix(nesti_model_t* m, int mask) {
+  if (!m) NESTI_FAIL("nesti_model_set_expert_mix: null model");
+  if (mask && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_expert_mix: pair-mode experts_n_est models (8^3 grid) only");
+  if (mask < 0 || mask >= (1 << 6)) NESTI_FAIL("nesti_model_set_expert_mix: mask has six bits");
+  m->expert_mix = mask;
+  return 0;
+}
+
 int nesti_model_cascade_stats(const nesti_model_t* m, nesti_cascade_stats_t* out, int reset, void* stream) {
   if (!m || !m->cascade || !out) NESTI_FAIL("nesti_model_cascade_stats: not a NESTI_F16X3C model");
   unsigned long long h[8];
@@ -1102,6 +1138,16 @@ int nesti_model_cascade_stats(const nesti_model_t* m, nesti_cascade_stats_t* out
   out->widen_events = h[7];
   out->tau_eff = std::max(m->tau, NESTI_GATE_WIDEN * out->max_margin_err);
   return 0;
+}
+
+int nesti_model_gate_error_export(const nesti_model_t* m, float* dst_dev, void* stream) {
+  if (!m || !m->cascade || !dst_dev) NESTI_FAIL("nesti_model_gate_error_export: not a NESTI_F16X3C model / null argument");
+  return launch_gate_error_export(m->cstat, dst_dev, (hipStream_t)stream);
+}
+
+int nesti_model_gate_error_import(nesti_model_t* m, const float* src_dev, int n, void* stream) {
+  if (!m || !m->cascade || (n > 0 && !src_dev)) NESTI_FAIL("nesti_model_gate_error_import: not a NESTI_F16X3C model / null argument");
+  return launch_gate_error_import(m->cstat, src_dev, n, (hipStream_t)stream);
 }
 
 size_t nesti_tower_workspace_bytes(const nesti_config_t* cfg, int dtype, int tower, int batch) {

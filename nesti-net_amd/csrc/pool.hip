@@ -174,10 +174,12 @@ __global__ void gate_finish_kernel(const float* __restrict__ logits, int lstride
 // The margin REACTS to what the gate measures (it does not just report it): the threshold of a forward call is
 //   tau_eff = max(tau, NESTI_GATE_WIDEN * max_margin_err so far),
 // snapshotted into the call's workspace by gate_begin_kernel (forward calls on other streams share the counters and may raise
-// them while this one runs), and after the call's own recheck rounds gate_widen_kernel flags the band
-// [tau_eff, NESTI_GATE_WIDEN * max_margin_err) once more, so that an error the call has just measured is already covered for
-// the rows of the same call.  Unrechecked rows therefore keep a margin of at least NESTI_GATE_WIDEN x the largest error seen
-// on any row decided twice since the counters were last reset.
+// them while this one runs), and after the call's own recheck rounds up to NESTI_GATE_WIDEN_PASSES widening passes flag the band
+// [tau_eff, NESTI_GATE_WIDEN * max_margin_err) again, each against a snapshot taken when it starts, so that an error the call
+// has just measured -- in its recheck rounds or in an earlier widening pass -- is covered for the rows of the same call.
+// Unrechecked rows therefore keep a margin of at least NESTI_GATE_WIDEN x the largest error seen on any row decided twice up to
+// the start of the call's last widening pass.  The guarantee is per call: two calls in flight on two streams share the
+// counters, and an error one of them measures after the other's last snapshot protects the other only from its next call on.
 __global__ void gate_begin_kernel(int32_t* __restrict__ fcounts, const unsigned long long* __restrict__ cstat, float tau,
                                   float widen) {
   if (threadIdx.x != 0) return;
@@ -236,14 +238,24 @@ __global__ void gate_flag_kernel(const float* __restrict__ logits, int lstride, 
   }
 }
 
-// The widening round's flag list: rows whose f16 margin lies in [tau_eff, widen * max_margin_err) -- normally nobody.  Runs
-// after the call's recheck rounds, on the kept f16 logits; the first list is dead by then and its storage is reused.
-__global__ void gate_widen_kernel(const float* __restrict__ keep, int B, int E, float widen, int32_t* __restrict__ fcounts,
+// One widening pass (model.hip: gate_cascade runs up to NESTI_GATE_WIDEN_PASSES of them after the recheck rounds, each normally
+// empty).  gate_widen_begin_kernel snapshots the pass's upper bound = widen x the largest error measured so far -- by this call's
+// own recheck rounds or by calls on other streams -- into the call's workspace, so that every thread of the pass flags against
+// the same band; gate_widen_kernel appends the rows whose f16 margin lies in [tau_eff, upper) to the flag list (the previous
+// list is dead by then, its storage is reused); gate_widen_end_kernel writes the tower-round counts and raises the call's tau_eff
+// to `upper`, so the next pass starts where this one ended: an error first measured INSIDE a widening pass is covered by the
+// following pass of the same call.
+__global__ void gate_widen_begin_kernel(int32_t* __restrict__ fcounts, const unsigned long long* __restrict__ cstat, float widen) {
+  if (threadIdx.x != 0) return;
+  fcounts[kWidenCountOff] = 0;
+  reinterpret_cast<float*>(fcounts)[kWidenUpperOff] = widen * __uint_as_float((unsigned)cstat[3]);
+}
+__global__ void gate_widen_kernel(const float* __restrict__ keep, int B, int E, int32_t* __restrict__ fcounts,
                                   int32_t* __restrict__ flag_list, unsigned long long* __restrict__ cstat) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   const float lower = reinterpret_cast<const float*>(fcounts)[kTauEffOff];
-  const float upper = widen * __uint_as_float((unsigned)cstat[3]);
+  const float upper = reinterpret_cast<const float*>(fcounts)[kWidenUpperOff];
   if (!(upper > lower)) return;
   float l[NESTI_MAX_EXPERTS];
   for (int e = 0; e < E; ++e) l[e] = keep[(size_t)b * NESTI_MAX_EXPERTS + e];
@@ -255,6 +267,25 @@ __global__ void gate_widen_kernel(const float* __restrict__ keep, int B, int E, 
   atomicAdd(&cstat[1], 1ull);
   atomicAdd(&cstat[6], 1ull);
   if (pos == 0) atomicAdd(&cstat[7], 1ull);
+}
+__global__ void gate_widen_end_kernel(int32_t* __restrict__ fcounts, int cap, int n_rounds) {
+  const int t = threadIdx.x;
+  if (t < n_rounds) fcounts[kWidenRoundsOff + t] = max(0, min(cap, fcounts[kWidenCountOff] - t * cap));
+  if (t == 0) {
+    float* f = reinterpret_cast<float*>(fcounts);
+    if (f[kWidenUpperOff] > f[kTauEffOff]) f[kTauEffOff] = f[kWidenUpperOff];
+  }
+}
+
+// multi-GPU: the largest error of the f16 gate as a device float, and the other ranks' values folded back in (dist.py)
+__global__ void gate_error_export_kernel(const unsigned long long* __restrict__ cstat, float* __restrict__ dst) {
+  if (threadIdx.x == 0) dst[0] = __uint_as_float((unsigned)cstat[3]);
+}
+__global__ void gate_error_import_kernel(unsigned long long* __restrict__ cstat, const float* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = src[i];
+  if (v > 0.f && v < INFINITY) atomicMax(&cstat[3], (unsigned long long)__float_as_uint(v));   // NaN compares false
 }
 
 // rows [r * cap, r * cap + cap) of list i are one round of a tower that runs `cap` rows at a time:
@@ -409,9 +440,21 @@ int launch_gate_widen(const float* keep, int B, int E, float widen, int32_t* fco
                       unsigned long long* cstat, hipStream_t stream) {
   if (B <= 0) return 0;
   if (n_rounds > kMaxCascadeRounds) NESTI_FAIL("gate_widen: too many rounds");
-  hipLaunchKernelGGL(gate_widen_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, keep, B, E, widen, fcounts, flag_list, cstat);
-  hipLaunchKernelGGL(round_counts_kernel, dim3(1), dim3(64), 0, stream, fcounts + kWidenCountOff, 1, cap, n_rounds,
-                     fcounts + kWidenRoundsOff);
+  hipLaunchKernelGGL(gate_widen_begin_kernel, dim3(1), dim3(64), 0, stream, fcounts, cstat, widen);
+  hipLaunchKernelGGL(gate_widen_kernel, dim3((B + 255) / 256), dim3(256), 0, stream, keep, B, E, fcounts, flag_list, cstat);
+  hipLaunchKernelGGL(gate_widen_end_kernel, dim3(1), dim3(64), 0, stream, fcounts, cap, n_rounds);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gate_error_export(const unsigned long long* cstat, float* dst, hipStream_t stream) {
+  hipLaunchKernelGGL(gate_error_export_kernel, dim3(1), dim3(64), 0, stream, cstat, dst);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int launch_gate_error_import(unsigned long long* cstat, const float* src, int n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gate_error_import_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cstat, src, n);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }

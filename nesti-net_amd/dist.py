@@ -5,7 +5,13 @@ Query points are independent at inference (BN uses stored EMA statistics,
 ``utils/tf_util.py:491-493``), so a shape's patch rows are block-partitioned across ranks --
 contiguous ranges keep output order = file order -- the cloud and the weights are replicated,
 and the only exchange is ONE all-gather of the per-shard results per shape
-(normals 3 + expert 1 + probs E floats per point, ~4.4 MB for 100k points)."""
+(normals 3 + expert 1 + probs E floats per point, ~4.4 MB for 100k points).
+
+dtype 'f16x3c': the gather buffer carries one spare row per rank holding that rank's ``max_margin_err`` (the largest
+error its f16 gate filter has shown); after the gather every rank folds all of them into its own counter
+(``NestiNet.export_gate_error`` / ``import_gate_error``: two one-thread kernels, no host synchronisation, no extra
+collective), so from the next step on ALL ranks filter with the same ``tau_eff`` = 1.5 x the largest error any rank has
+measured."""
 import torch
 import torch.distributed as dist
 
@@ -26,24 +32,43 @@ def agree_on_gate_margin(net, tau, device, group=None):
     whose order differs from run to run, so the ranks' values may differ in their last bits.  All ranks adopt the largest one
     (one scalar all-reduce, outside any timed region).  Returns (tau everyone uses, max - min over the ranks)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return float(tau), 0.0
-    t = torch.tensor([float(tau), -float(tau)], dtype=torch.float64, device=device)
+        return min(float(tau), 1e30), 0.0
+    big = 1e30                                     # calibrate_gate_margin's "no filtering" value (tau = inf is not JSON)
+    tau = min(float(tau), big)
+    t = torch.tensor([tau, -tau], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     hi, lo = float(t[0].item()), -float(t[1].item())
-    net.set_gate_margin(hi if hi < 1e30 else 1e30)
-    return hi, hi - lo
+    net.set_gate_margin(hi)
+    return hi, (hi - lo if hi < big else 0.0)
 
 
 _BUFFERS = {}
 
 
 def _buffers(world, rows, cols, device):
-    """Preallocated send [rows, cols] / receive [world, rows, cols] f32 buffers, reused from shape to shape."""
+    """Preallocated send [rows + 1, cols] / receive [world, rows + 1, cols] f32 buffers, reused from shape to shape.  Row
+    ``rows`` is the spare row: element 0 carries the rank's gate error (dtype 'f16x3c'), zero otherwise."""
     key = (world, rows, cols, str(device))
     if key not in _BUFFERS:
-        _BUFFERS[key] = (torch.zeros((rows, cols), dtype=torch.float32, device=device),
-                         torch.empty((world, rows, cols), dtype=torch.float32, device=device))
+        _BUFFERS[key] = (torch.zeros((rows + 1, cols), dtype=torch.float32, device=device),
+                         torch.empty((world, rows + 1, cols), dtype=torch.float32, device=device))
     return _BUFFERS[key]
+
+
+def _cascade_net(estimator):
+    """The estimator's model when it runs the two-stage gate (its error counter takes part in the gather), else None."""
+    net = getattr(estimator, "net", None)
+    return net if getattr(net, "cascade", False) else None
+
+
+def _all_gather(mine, everyone, rows, net, group):
+    """THE collective of the path; ``net`` (a cascade model or None): its gate error rides in the spare row."""
+    world, _, cols = everyone.shape
+    if net is not None:
+        net.export_gate_error(mine[rows, 0:1])
+    dist.all_gather_into_tensor(everyone.view(world * (rows + 1), cols), mine, group=group)
+    if net is not None:
+        net.import_gate_error(everyone[:, rows, 0].contiguous())
 
 
 def pack_results(normals, expert, probs, out):
@@ -62,7 +87,7 @@ def unpack_results(buf, gated=True):
     return buf[:, 0:3].contiguous(), buf[:, 3].contiguous().view(torch.int32), buf[:, 4:].contiguous()
 
 
-def gather_shards(normals, expert, probs, n_rows, group=None):
+def gather_shards(normals, expert, probs, n_rows, group=None, net=None):
     """All-gather the per-rank shard results of one shape into full-length tensors on every rank: ONE
     ``all_gather_into_tensor`` on a preallocated [world, max_shard, 3 (+1+E)] buffer (RCCL ring over xGMI; ~4.4 MB
     for a 100k-point cloud, latency-bound).  Single-tower models (ss_norm_est / ms_norm_est) have no expert/probs
@@ -75,9 +100,7 @@ def gather_shards(normals, expert, probs, n_rows, group=None):
     ms = max_shard(n_rows, world)
     mine, everyone = _buffers(world, ms, cols, normals.device)
     pack_results(normals, expert, probs, mine)
-    dist.all_gather_into_tensor(everyone.view(world * ms, cols), mine, group=group)   # the single collective of the path
-    if n_rows == world * ms:                       # equal shards: the receive buffer already is the result
-        return unpack_results(everyone.view(world * ms, cols), gated)
+    _all_gather(mine, everyone, ms, net, group)                                       # the single collective of the path
     outs = []
     for r in range(world):
         lo, hi = shard_range(n_rows, r, world)
@@ -91,7 +114,7 @@ def estimate_sharded(estimator, cloud, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lo, hi = shard_range(cloud.patch_count, rank, world)
     normals, expert, probs = estimator.run(cloud, lo, hi - lo)
-    return gather_shards(normals, expert, probs, cloud.patch_count, group)
+    return gather_shards(normals, expert, probs, cloud.patch_count, group, net=_cascade_net(estimator))
 
 
 def estimate_sharded_many(estimator, clouds, group=None):
@@ -115,7 +138,7 @@ def estimate_sharded_many(estimator, clouds, group=None):
     mine, everyone = _buffers(world, offs[-1], cols, outs[0][0].device)
     for (n, e, p), o in zip(outs, offs):
         pack_results(n, e, p, mine[o:])
-    dist.all_gather_into_tensor(everyone.view(world * offs[-1], cols), mine, group=group)     # the single collective of the step
+    _all_gather(mine, everyone, offs[-1], _cascade_net(estimator), group)                     # the single collective of the step
     res = []
     for ci, c in enumerate(clouds):
         parts = []

@@ -117,8 +117,8 @@ class NestiNet:
         """Counters of the two-stage gate since the last reset (synchronises the stream): dict with queries, rechecked,
         changed, max_margin_err (the f16 gate's largest error on a logit difference among the rechecked queries), sigma
         (the standard deviation of that error over all rechecked (query, expert) pairs), tau, and the self-widening
-        counters: widened (queries re-decided by a widening round), widen_events (forward calls with a non-empty
-        widening round) and tau_eff = max(tau, 1.5 x max_margin_err), the threshold the next call starts from."""
+        counters: widened (queries re-decided by a widening pass), widen_events (widening passes that were not empty;
+        a call runs up to ``_lib.GATE_WIDEN_PASSES``) and tau_eff = max(tau, 1.5 x max_margin_err), the threshold the next call starts from."""
         st = _lib.CCascadeStats()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.nesti_model_cascade_stats(self._handle, ctypes.byref(st), int(bool(reset)), self._stream(stream)),
@@ -127,6 +127,23 @@ class NestiNet:
         return {"queries": int(st.queries), "rechecked": int(st.rechecked), "changed": int(st.changed),
                 "max_margin_err": float(st.max_margin_err), "sigma": float(sigma), "tau": float(st.tau),
                 "widened": int(st.widened), "widen_events": int(st.widen_events), "tau_eff": float(st.tau_eff)}
+
+    def set_expert_mix(self, mask):
+        """EXPERIMENT: which expert tap layers run a single 16-bit product (``nesti_model_set_expert_mix``; 0 = none)."""
+        _lib.check(self.lib.nesti_model_set_expert_mix(self._handle, int(mask)), "nesti_model_set_expert_mix")
+
+    def export_gate_error(self, dst, stream=None):
+        """Write this model's ``max_margin_err`` into the one-element f32 device tensor ``dst`` (no synchronisation)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_model_gate_error_export(self._handle, _lib.ptr(dst), self._stream(stream)),
+                       "nesti_model_gate_error_export")
+
+    def import_gate_error(self, src, stream=None):
+        """Raise ``max_margin_err`` to the largest finite value of the contiguous f32 device tensor ``src`` (other ranks'
+        measurements, ``dist.py``): the next call's ``tau_eff`` then covers the largest error ANY rank has seen."""
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_model_gate_error_import(self._handle, _lib.ptr(src), int(src.numel()), self._stream(stream)),
+                       "nesti_model_gate_error_import")
 
     # -- workspace -------------------------------------------------------------------------
     def reserve(self, batch):

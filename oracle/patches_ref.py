@@ -45,8 +45,10 @@ def build_tree(pts):
     return spatial.cKDTree(pts, 10)      # utils/pcpnet_dataset.py:37
 
 
-def extract_patches(pts, query_idx, r_abs, P, seed, tree=None):
-    """pts [N,3] float32; query_idx [M]; r_abs list of S python floats.
+def extract_patches(pts, query_idx, r_abs, P, seed, tree=None, rows=None):
+    """pts [N,3] float32; query_idx [M]; r_abs list of S python floats; ``rows`` [M]: the patch-row number of each query
+    within its shape, which keys the documented subsample (default: its position in ``query_idx``, i.e. a shape whose
+    patch rows are exactly these queries in this order).
 
     Returns points [M,S*P,3] f32, n_eff [M,S] i32, nbr [M,S*P] i32 (-1 padded),
     n_ball [M,S] i32 (uncapped ball sizes)."""
@@ -64,7 +66,7 @@ def extract_patches(pts, query_idx, r_abs, P, seed, tree=None):
             n_ball[q, s] = len(inds)
             count = min(P, len(inds))                                # :310
             n_eff[q, s] = count
-            h = subsample_hash(seed, q, s, inds)
+            h = subsample_hash(seed, q if rows is None else int(rows[q]), s, inds)
             order = np.lexsort((inds, h))[:count]                    # documented subsample rule
             inds = inds[order]
             start = s * P

@@ -16,6 +16,10 @@ DT = {"f32": "0", "bf16": "1", "f16": "2", "f16x3": "2", "f16x3c": "2", "bf16x3"
 
 
 def family(k):
+    # the fused product-path kernel first: its template argument is the OUTPUT dtype (4 = the f16 pair layout), not a conv
+    # element type, and its name contains "mups_kernel" (the row used to be dropped by the filter below)
+    if "patches_mups_kernel" in k:
+        return "patches_mups_kernel"
     m = re.search(r"(conv8n_kernel|conv4n_kernel|conv_igemm_kernel|mups_kernel|maxpool2_kernel)<(\d)", k)
     if m:
         if m.group(2) != DT:

@@ -112,6 +112,80 @@ def test_every_rank_adopts_the_same_gate_margin_world_8():
     assert all(abs(s - 7e-9) < 1e-12 and nt == t for _, t, s, nt in res)
 
 
+class _FakeCascadeNet:
+    """Stands in for an 'f16x3c' NestiNet: one float of gate error out, the other ranks' floats in."""
+    cascade = True
+
+    def __init__(self, err):
+        self.err = float(err)
+
+    def export_gate_error(self, dst):
+        dst[0] = self.err
+
+    def import_gate_error(self, src):
+        assert src.is_contiguous()
+        v = src[torch.isfinite(src)]
+        self.err = max(self.err, float(v.max())) if len(v) else self.err
+
+
+class _FakeCascadeEstimator(_FakeEstimator):
+    def __init__(self, err):
+        self.net = _FakeCascadeNet(err)
+
+    def run(self, cloud, first, count):
+        return self.run_many([(cloud, first, count)])[0]
+
+
+def _worker_gate_error(rank, world, port, q):
+    import sys
+    sys.path.insert(0, REPO)
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import dist as nd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    est = _FakeCascadeEstimator(0.05 + 0.01 * ((rank * 5) % world))          # every rank has measured a different error
+    res = nd.estimate_sharded_many(est, [_FakeCloud(1001), _FakeCloud(3)])
+    after_many = est.net.err
+    est.net.err = 0.2 if rank == 1 else 0.0                                   # a widening event on ONE rank ...
+    n, e, p = nd.estimate_sharded(est, _FakeCloud(77))                        # ... reaches everyone with the next gather
+    rows = np.arange(77, dtype=np.float32) + 77000.0
+    ok = np.array_equal(n.numpy(), np.stack([rows, rows * 2, rows * 3], 1)) and len(res[0][0]) == 1001
+    q.put((rank, after_many, est.net.err, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gate_error_rides_in_the_gather(world):
+    """after a widening event all ranks filter with ONE tau_eff -- the largest f16-gate error any
+    rank has measured travels in a spare row of the step's single all-gather (no collective of its own)."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_gate_error, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, after_many, after_one, ok in res:
+        assert ok
+        assert abs(after_many - (0.05 + 0.01 * (world - 1))) < 1e-6, (rank, after_many)
+        assert abs(after_one - 0.2) < 1e-6, (rank, after_one)
+
+
+def test_gate_margin_at_infinity_is_json_safe():
+    """fewer than 256 calibration queries leave tau at infinity; the agreed value and the spread must stay finite."""
+    import json
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import dist as nd
+    net = _FakeNet()
+    tau, spread = nd.agree_on_gate_margin(net, float("inf"), torch.device("cpu"))
+    assert tau == 1e30 and spread == 0.0
+    json.loads(json.dumps({"tau": tau, "spread": spread}, allow_nan=False))
+
+
 @pytest.mark.parametrize("sizes,world", [([1001, 64, 500], 2),
                                          # world size 8 (the north star's node): sizes not divisible by 8, a cloud with fewer
                                          # rows than ranks (three ranks get nothing of it), an empty cloud, equal shards

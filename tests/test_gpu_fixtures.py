@@ -106,7 +106,9 @@ def test_f32_path_matches_oracle_across_fixture_cloud(name, gpu_device):
     from nesti_net_amd import parity
     print(name, "F32_PROB_ERR on this fixture %.4g (bound %.4g, TIE_MARGIN %.4g)" % (perr, parity.F32_PROB_ERR_BOUND, parity.TIE_MARGIN))
     assert perr <= parity.F32_PROB_ERR_BOUND
-    assert np.all(agree | (margin < 2e-5))            # arg-max exact unless the fp64 oracle's own top-2 are tied to 2e-5
+    # ONE tie rule for suite, smoke and bench (parity.TIE_MARGIN); differences the old hand-picked 2e-5 would not excuse are printed
+    print(name, "f32 flips with an oracle gap in [%.0e, TIE_MARGIN): %d" % (parity.TIE_MARGIN_HAND, int((~agree & (margin >= parity.TIE_MARGIN_HAND)).sum())))
+    assert np.all(agree | (margin < parity.TIE_MARGIN))   # arg-max exact unless the fp64 oracle's own top-2 are tied at fp32 level
     assert np.all(1 - c < 1e-5)
     # ---- the same rows in the f16x3 pair mode (the north-star mode of the bench) against the same oracle results ----
     del net
@@ -117,7 +119,8 @@ def test_f32_path_matches_oracle_across_fixture_cloud(name, gpu_device):
     c3 = _cos(n3.cpu().numpy()[agree3], ref["normals"][agree3])
     print(name, "f16x3: prob err", perr3, "flips", int((~agree3).sum()), "1-cos max", (1 - c3).max())
     assert perr3 < 1e-4
-    assert np.all(agree3 | (margin < 2e-5))
+    print(name, "f16x3 flips with an oracle gap in [%.0e, TIE_MARGIN): %d" % (parity.TIE_MARGIN_HAND, int((~agree3 & (margin >= parity.TIE_MARGIN_HAND)).sum())))
+    assert np.all(agree3 | (margin < parity.TIE_MARGIN))
     assert np.all(1 - c3 < 1e-5)
     # ---- ... and in f16x3c, the headline mode: f16x3 behind the two-stage gate, its margin calibrated on this fixture's own
     # queries (>= 256, as bench.py does on the timed cloud), against the SAME fp64 oracle results ------------------------------
@@ -133,7 +136,7 @@ def test_f32_path_matches_oracle_across_fixture_cloud(name, gpu_device):
     print(name, "f16x3c: tau %.4g" % tau, st, "flips", int((~agree_c).sum()), "prob err (rechecked rows / all)",
           perr_c[twice].max() if twice.any() else 0.0, perr_c.max(), "1-cos max", (1 - cc).max())
     assert np.isfinite(tau) and 0 < st["rechecked"] < len(q) and st["queries"] == len(q)
-    assert np.all(agree_c | (margin < 2e-5))                 # arg-max exact against the oracle, like f32 and f16x3 above
+    assert np.all(agree_c | (margin < parity.TIE_MARGIN))    # arg-max exact against the oracle, like f32 and f16x3 above
     assert np.array_equal(ec.cpu().numpy(), e3.cpu().numpy())   # ... and identical to f16x3's on every query
     assert torch.equal(nc, n3)                               # the experts always run in f16x3
     assert np.all(1 - cc < 1e-5)
@@ -198,7 +201,7 @@ def test_pair_modes_meet_the_north_star_on_10k_queries(big_case, gpu_device, mod
     """dtype 'f16x3' / 'bf16x3' (activations and weights as 16-bit hi + lo pairs, three MFMA products per multiply) and
     'f16x3c' (f16x3 behind the two-stage gate, the bench's headline mode) against the exact-fp32 mode on the same 10 240
     queries: normals within 1e-5 cosine (test_n_est_w_experts.py's outputs to the north star's tolerance) and no arg-max
-    difference outside the fp32 reference's own 2e-5 tie margin (parity.py).  The f16 pair modes keep two orders of
+    difference outside the fp32 reference's own tie margin (parity.TIE_MARGIN = 2 x the measured f32-vs-fp64 probability error).  The f16 pair modes keep two orders of
     magnitude of headroom on the normals; bf16x3 (2^-17 operands) is at the edge of the tolerance (scripts/pair_mode_sweep.py)
     and is only held to its measured distribution."""
     from nesti_net_amd import parity

@@ -34,7 +34,7 @@ def _golden(name, rows):
 
 @pytest.mark.parametrize("mode", MODES)
 def test_pair_mode_matches_the_fp64_oracle_on_golden_patches(mode, gpu_device):
-    from nesti_net_amd import weights
+    from nesti_net_amd import parity, weights
     from nesti_net_amd.config import NestiConfig
     from nesti_net_amd.model import NestiNet
     from oracle import mups_ref, net_ref
@@ -65,7 +65,7 @@ def test_pair_mode_matches_the_fp64_oracle_on_golden_patches(mode, gpu_device):
     ca = _cos(n_est, full["n_est"].numpy())
     print(mode, "vs oracle: prob err", pe, "agree", agree.mean(), "1-cos max", (1 - c).max(), "all experts", (1 - ca).max())
     assert pe < (1e-3 if mode == "bf16x3" else 1e-4)  # 2^-17 operands on O(10) logits; f16 pairs: like the fp32 mode
-    assert np.all(agree | (margin < (2e-3 if mode == "bf16x3" else 2e-5)))
+    assert np.all(agree | (margin < (2e-3 if mode == "bf16x3" else parity.TIE_MARGIN)))
     assert np.all(1 - c < COS_TOL) and np.all(1 - ca < COS_TOL)
     if mode == "f16x3":
         assert (1 - c).max() < 1e-7 and (1 - ca).max() < 1e-7
