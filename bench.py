@@ -586,8 +586,16 @@ def main():
                 # put the differing queries to the fp64 oracle (checker only)
                 adj = adjudicate_flips(cfg, W, clouds_np[0][0], res["parity"]["flip_rows"], main_run["shard0"], ref)
                 res["parity"]["adjudication"] = adj
-                res["parity"]["meets_north_star"] = bool(res["parity"]["meets_north_star"] and adj["all_ties"])
-                res["parity"]["meets_north_star_at_2e-5"] = bool(res["parity"]["meets_north_star_at_2e-5"] and adj["all_ties_at_2e-5"])
+                # the oracle's gap is the authority on what a tie is (it is the rule tests/ hold the f32 mode itself to); it can
+                # only be trusted for the rows it saw (flip_rows is capped at 64)
+                seen_all = res["parity"]["argmax_flips"] <= len(adj["flips"])
+                cos_ok = res["parity"]["one_minus_cos"]["max"] <= res["parity"]["cos_tol"]
+                res["parity"]["meets_north_star"] = bool(cos_ok and seen_all and adj["all_ties"])
+                res["parity"]["meets_north_star_at_2e-5"] = bool(cos_ok and seen_all and adj["all_ties_at_2e-5"])
+                res["parity"]["verdict_rule"] = ("1 - cos <= cos_tol on every query whose arg-max agrees, and every arg-max difference "
+                                                 "is a query whose fp64-ORACLE top-2 gap is below tie_margin (meets_north_star) / "
+                                                 "below 2e-5 (meets_north_star_at_2e-5); flips_outside_margin / "
+                                                 "flips_gap_hand_to_margin count the same differences by the f32 mode's own gap")
             # the exact-fp32 MFMA mode is the one the CPU oracle is tied to (tests/test_gpu_fixtures.py); its rate on the same
             # cloud, one untimed-style pass
             res["exact_mode"] = {"dtype": "f32", "value": ref_rate, "unit": "normals/sec (1 GPU, one pass over rank 0's shard)",

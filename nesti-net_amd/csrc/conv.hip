@@ -257,7 +257,11 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
     stage_b(0, 0, 0);
     wait_vm0();
     __syncthreads();
+#ifdef IGEMM_NO_MAIN      // timing-only experiment (wrong results): the epilogue alone
+    for (int c = 0; c < 0; ++c) {
+#else
     for (int c = 0; c < p.n_chunks; ++c) {
+#endif
       const int cur = c & 1;
       if (c + 1 < p.n_chunks) {
         stage_a(c + 1, cur ^ 1);
@@ -311,6 +315,19 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   }
 
   // ---- epilogue (the barrier that ended the last step guarantees nobody still reads A/B) -------
+#ifdef IGEMM_NO_EPILOGUE  // timing-only experiment (wrong results): the main loop alone (the accumulators stay live through a
+  if (KPIPE) {            // store that never happens)
+    float sink = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sink += acc[mi][ni][r];
+    if (sink == 1.2345e-31f) reinterpret_cast<float*>(p.out)[0] = sink;
+    return;
+  }
+#endif
   const int out_esz = p.out_f32 ? 4 : kEsz;
   unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
   const bool second = n_tile >= p.split_tile;            // conv4 half of a merged conv1|conv4 launch

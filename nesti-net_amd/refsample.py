@@ -6,8 +6,8 @@ reference keeps ``rng.choice(n, P, replace=False)`` of scipy's cKDTree traversal
 stream shared by every patch and scale of every shape in visiting order (``utils/pcpnet_dataset.py:237-240, 304,
 320-321``).  On PCPNet's 100k clouds the largest scale overflows on every patch, so only this path can reproduce a real
 reference run's ``.normals`` row for row: it restates ``__getitem__`` (``utils/pcpnet_dataset.py:286-343``, center =
-'point', use_pca = False, point_tuple = 1, point_count_std = 0) with scipy and numpy on the host -- about a millisecond
-per patch, like the reference -- and feeds the patch tensors to the same ``nesti_forward`` as everything else.
+'point', use_pca = False, point_tuple = 1, point_count_std = 0) with scipy and numpy on the host -- batched per library batch: ~0.2 ms per patch on 8 cores, most of it scipy's
+ball query (the reference's per-patch Python loop takes 0.46 ms on one core here) -- and feeds the patch tensors to the same ``nesti_forward`` as everything else.
 
 Pinned by ``tests/test_refsample.py``: the golden fixtures hold the reference dataset's patch tensors for queries
 visited in order with its seed, capped balls included; this module reproduces them bit for bit.
@@ -19,6 +19,13 @@ from scipy import spatial
 
 REFERENCE_SEED = 3627473          # test_n_est_w_experts.py:113
 
+# cKDTree.query_ball_point(..., return_sorted=False, workers=-1) needs scipy >= 1.6: fail at import with a clear
+# message instead of a TypeError deep inside a run
+import scipy  # noqa: E402
+scipy_version = tuple(int(x) for x in scipy.__version__.split(".")[:2] if x.isdigit())
+if scipy_version < (1, 6):
+    raise ImportError("nesti_net_amd.refsample needs scipy >= 1.6 (query_ball_point return_sorted / workers), found %s" % scipy.__version__)
+
 
 class ReferencePatchSampler:
     """Holds the random stream of one reference ``PointcloudPatchDataset`` (``utils/pcpnet_dataset.py:237-240``).
@@ -28,6 +35,8 @@ class ReferencePatchSampler:
     def __init__(self, seed=REFERENCE_SEED):
         self.seed = int(seed)
         self.rng = np.random.RandomState(self.seed)
+        self._bufs = {}            # (M, S, P) -> (points, idx): reused from batch to batch (first-touch page faults of a fresh
+                                   # 180 MB tensor cost as much as the arithmetic that fills it)
 
     @staticmethod
     def build_tree(pts):
@@ -35,7 +44,8 @@ class ReferencePatchSampler:
 
     def patches(self, pts, tree, center_inds, r_abs, P):
         """``pts`` [N,3] float32, ``center_inds`` [M] point indices (the shape's .pidx rows or a range), ``r_abs`` the
-        absolute radii (Python floats, :282) -> points [M, S*P, 3] float32, n_eff [M, S] int32.
+        absolute radii (Python floats, :282) -> points [M, S*P, 3] float32, n_eff [M, S] int32.  ``points`` is a buffer the
+        sampler reuses for the next call with the same M: copy (or upload) it before asking for the next batch.
 
         Batched: ONE ``query_ball_point`` per scale for all M centres (all cores; ``return_sorted=False`` keeps cKDTree's
         traversal order, which is what a single-point query returns and what the reference subsamples), then the shared
@@ -46,13 +56,16 @@ class ReferencePatchSampler:
         pts = np.ascontiguousarray(pts, dtype=np.float32)
         center_inds = np.asarray(center_inds, dtype=np.int64)
         M, S = len(center_inds), len(r_abs)
-        points = np.zeros((M, S * P, 3), np.float32)                        # :298 (.zero_())
         n_eff = np.zeros((M, S), np.int32)
         if M == 0:
-            return points, n_eff
+            return np.zeros((0, S * P, 3), np.float32), n_eff
+        if (M, S, P) not in self._bufs:
+            self._bufs = {(M, S, P): (np.empty((M, S * P, 3), np.float32), np.empty((M, P), np.int32))}
+        points, idx = self._bufs[(M, S, P)]      # every element is overwritten below (:298's zero rows included); the caller
+                                                 # must be done with the previous batch's tensor, see NormalEstimator
         centers = pts[center_inds]
         balls = [tree.query_ball_point(centers, rad, return_sorted=False, workers=-1) for rad in r_abs]     # :304, all centres
-        sizes = np.array([[len(balls[s][i]) for s in range(S)] for i in range(M)], dtype=np.int64).reshape(M, S)
+        sizes = np.stack([np.fromiter(map(len, balls[s]), dtype=np.int64, count=M) for s in range(S)], axis=1)
         n_eff[:] = np.minimum(sizes, P)                                     # :310-311
         # the random stream, in visiting order; only over-full balls draw from it (:320-321)
         choice = self.rng.choice
@@ -65,12 +78,13 @@ class ReferencePatchSampler:
         for i, s in zip(*np.nonzero(over)):                                 # row-major = patch-major, scale-minor
             picks[s][fill[s]] = choice(int(sizes[i, s]), P, replace=False)
             fill[s] += 1
-        ar = np.arange(P)
         for s, rad in enumerate(r_abs):
             # all balls of the scale flattened in one pass (row order, traversal order within a row)
             flat = np.fromiter(itertools.chain.from_iterable(balls[s]), dtype=np.int64, count=int(sizes[:, s].sum()))
+            balls[s] = None                                                 # the Python lists of this scale are no longer needed
             off = np.cumsum(sizes[:, s]) - sizes[:, s]
-            idx = np.zeros((M, P), np.int64)                                # neighbour indices row by row; padding -> point 0
+            # neighbour indices row by row; a padding slot points at the centre itself: (c - c) / r = +0.0, the zero row of :298
+            idx[:] = center_inds[:, None]
             small = np.nonzero(~over[:, s])[0]
             cnt = sizes[small, s]
             rows = np.repeat(small, cnt)
@@ -79,7 +93,8 @@ class ReferencePatchSampler:
             if len(pick_rows[s]):
                 idx[pick_rows[s]] = flat[off[pick_rows[s]][:, None] + picks[s]]
             # :330-343: float32 gather, minus the centre, divided by the radius as a float32 scalar; rows beyond n_eff stay zero
-            block = (pts[idx] - centers[:, None, :]) / np.float32(rad)
-            block[ar[None, :] >= n_eff[:, s:s + 1]] = 0
-            points[:, s * P:(s + 1) * P] = block
+            # (ndarray.take on the flattened index list is ~10x faster than fancy-indexing with the 2-D index array)
+            dst = points[:, s * P:(s + 1) * P]
+            np.subtract(pts.take(idx.ravel(), axis=0).reshape(M, P, 3), centers[:, None, :], out=dst)
+            np.divide(dst, np.float32(rad), out=dst)
         return points, n_eff

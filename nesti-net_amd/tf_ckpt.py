@@ -180,6 +180,12 @@ def _read_block(data, offset, size, verify=True):
 
 def read_index(index_path):
     """-> {variable name: BundleEntryProto dict} (the header entry with the empty key is dropped)."""
+    return read_index_and_header(index_path)[0]
+
+
+def read_index_and_header(index_path):
+    """-> ({variable name: BundleEntryProto dict}, {'num_shards': n}) -- the BundleHeaderProto sits on the empty key
+    (tensorflow/core/protobuf/tensor_bundle.proto: num_shards = 1, endianness = 2, version = 3)."""
     data = open(index_path, "rb").read()
     if len(data) < 48 or struct.unpack("<Q", data[-8:])[0] != TABLE_MAGIC:
         raise ValueError("%s is not a TensorFlow tensor-bundle index" % index_path)
@@ -188,28 +194,41 @@ def read_index(index_path):
     _, p = _varint(footer, p)
     idx_off, p = _varint(footer, p)
     idx_size, p = _varint(footer, p)
-    entries = {}
+    entries, header = {}, {"num_shards": 0}
     for _, handle in _read_block(data, idx_off, idx_size):
         off, q = _varint(handle, 0)
         size, q = _varint(handle, q)
         for key, val in _read_block(data, off, size):
             if key:
                 entries[key.decode()] = _parse_entry(val)
-    return entries
+            else:
+                for fn, wt, v in _fields(val):
+                    if fn == 1 and wt == 0:
+                        header["num_shards"] = int(v)
+                    elif fn == 2 and wt == 0 and v != 0:
+                        raise ValueError("%s was written on a big-endian host" % index_path)
+    if header["num_shards"] <= 0:          # no header entry (not a TF-written bundle): fall back to the entries' shard ids
+        header["num_shards"] = 1 + max([e["shard_id"] for e in entries.values()] + [0])
+    return entries, header
 
 
 def read_bundle(prefix, verify=True):
     """``saver.restore`` without TF: prefix e.g. ``.../model.ckpt`` -> {name: ndarray}.  ``verify``: check every tensor's
     stored crc32c like TF does on restore (an all-zero field means "not written" and is skipped)."""
-    entries = read_index(prefix + ".index")
+    entries, header = read_index_and_header(prefix + ".index")
+    n = header["num_shards"]                           # the data files are named after the HEADER's shard count (naming.cc)
     shards = {}
     out = {}
     for name, e in entries.items():
         if e["dtype"] not in _DTYPES:
             continue                                   # e.g. string tensors of the saver itself
         sid = e["shard_id"]
+        if sid >= n:
+            raise ValueError("tensor %s lives in shard %d but the bundle header declares %d shard(s)" % (name, sid, n))
+        if e["size"] == 0:
+            out[name] = np.zeros(e["shape"], _DTYPES[e["dtype"]])
+            continue
         if sid not in shards:
-            n = max(x["shard_id"] for x in entries.values()) + 1
             shards[sid] = np.memmap("%s.data-%05d-of-%05d" % (prefix, sid, n), dtype=np.uint8, mode="r")
         raw = np.asarray(shards[sid][e["offset"]:e["offset"] + e["size"]])
         if verify and e["crc32c"] != 0 and unmask_crc(e["crc32c"]) != crc32c(raw):

@@ -55,10 +55,12 @@ def test_two_ranks_on_one_gpu_match_single_process(model, tmp_path, gpu_device):
 
 
 def test_bench_two_ranks_debug_single_device(gpu_device):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+    """``python bench.py --gpus 2`` with NO launcher in the command (the shape of the driver's N = 1 command):
+    bench.py starts its two ranks itself as children of torch.distributed.run and forwards rank 0's line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
            "--points", "6000", "--batch", "2048", "--debug-single-device", "--no-cpu-baseline", "--no-secondary"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=REPO)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=REPO, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)

@@ -208,3 +208,199 @@ def test_corrupt_tensor_bytes_are_refused(tmp_path):
     with pytest.raises(ValueError, match="fails its crc32c"):
         tf_ckpt.read_bundle(prefix)
     assert tf_ckpt.read_bundle(prefix, verify=False)["a/weights"].shape == (3, 4)
+
+
+# ---- a whole TF-1.12-shaped checkpoint assembled from the published formats, without tests/ckpt_writer.py -------------------
+# (VERDICT r04 item 8).  Sources: leveldb/doc/table_format.md + table/block_builder.cc (entries = varint shared | varint
+# non_shared | varint value_len | key delta | value; restart array of fixed32 offsets + fixed32 count; block trailer = type byte
+# + masked crc32c; footer = metaindex handle | index handle, padded to 40 bytes, + 8-byte magic), tensorflow/core/protobuf/
+# tensor_bundle.proto (BundleHeaderProto on the empty key, BundleEntryProto per tensor) and tensorflow/core/util/
+# tensor_bundle/naming.cc (<prefix>.data-%05d-of-%05d).  Variable names are the ones TF 1.12 gives the reference's graph:
+# utils/tf_util.py:473-479 creates beta / gamma with tf.Variable inside variable_scope('<layer>/bn') and lets
+# tf.train.ExponentialMovingAverage shadow the OUTPUT TENSORS of tf.nn.moments; slot_creator opens
+# variable_scope(None, primary.op.name + '/ExponentialMovingAverage') INSIDE that scope, so the shadow of
+# '<layer>/bn/moments/Squeeze' is the variable '<layer>/bn/<layer>/bn/moments/Squeeze/ExponentialMovingAverage' (the scope
+# appears twice); AdamOptimizer (train_n_est_w_experts.py:182) adds '<var>/Adam', '<var>/Adam_1', 'beta1_power', 'beta2_power'.
+def _vint(v):
+    out = bytearray()
+    while True:
+        b = v & 0x7f
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _pb_entry(dtype, shape, shard, offset, size, crc_masked):
+    dims = b"".join(b"\x12" + _vint(len(d)) + d for d in (b"\x08" + _vint(n) for n in shape))     # repeated Dim {size = 1}
+    msg = b"\x08" + _vint(dtype) + b"\x12" + _vint(len(dims)) + dims
+    if shard:
+        msg += b"\x18" + _vint(shard)
+    if offset:
+        msg += b"\x20" + _vint(offset)
+    return msg + b"\x28" + _vint(size) + b"\x35" + struct.pack("<I", crc_masked)
+
+
+class _HandTable:
+    """A LevelDB table built straight from the format description: small blocks, restart points every 3 entries."""
+
+    def __init__(self, crc, mask, block_bytes=220, restart_every=3):
+        self.crc, self.mask, self.block_bytes, self.every = crc, mask, block_bytes, restart_every
+        self.file = bytearray()
+        self.index = []                        # (last key of the block, offset, size)
+        self._reset()
+
+    def _reset(self):
+        self.buf, self.restarts, self.n, self.last = bytearray(), [0], 0, b""
+
+    def add(self, key, value):
+        shared = 0
+        if self.n and self.n % self.every == 0:
+            self.restarts.append(len(self.buf))              # a restart point stores the full key
+        elif self.n:
+            while shared < min(len(key), len(self.last)) and key[shared] == self.last[shared]:
+                shared += 1
+        self.buf += _vint(shared) + _vint(len(key) - shared) + _vint(len(value)) + key[shared:] + value
+        self.last, self.n = key, self.n + 1
+        if len(self.buf) >= self.block_bytes:
+            self.flush()
+
+    def _emit(self, block):
+        off = len(self.file)
+        self.file += block + b"\x00" + struct.pack("<I", self.mask(self.crc(bytes(block) + b"\x00")))
+        return off, len(block)
+
+    def flush(self):
+        if not self.n:
+            return
+        block = bytes(self.buf) + b"".join(struct.pack("<I", r) for r in self.restarts) + struct.pack("<I", len(self.restarts))
+        self.index.append((self.last,) + self._emit(block))
+        self._reset()
+
+    def finish(self):
+        self.flush()
+        meta = self._emit(struct.pack("<II", 0, 1))          # empty metaindex block: one restart, no entries
+        ib = bytearray()
+        rs = []
+        for key, off, size in self.index:                    # index block: restart interval 1, value = BlockHandle
+            rs.append(len(ib))
+            h = _vint(off) + _vint(size)
+            ib += b"\x00" + _vint(len(key)) + _vint(len(h)) + key + h
+        idx = self._emit(bytes(ib) + b"".join(struct.pack("<I", r) for r in rs) + struct.pack("<I", len(rs)))
+        footer = (_vint(meta[0]) + _vint(meta[1]) + _vint(idx[0]) + _vint(idx[1])).ljust(40, b"\x00")
+        return bytes(self.file) + footer + struct.pack("<Q", 0xdb4775248b80fb57)
+
+
+def _tf112_names(layer, bn=True):
+    names = [layer + "/weights", layer + "/biases"]
+    if bn:
+        names += [layer + "/bn/beta", layer + "/bn/gamma",
+                  "%s/bn/%s/bn/moments/Squeeze/ExponentialMovingAverage" % (layer, layer),
+                  "%s/bn/%s/bn/moments/Squeeze_1/ExponentialMovingAverage" % (layer, layer)]
+    return names
+
+
+def _hand_checkpoint(tmp_path, layers, extra=()):
+    """-> (prefix, {tf name: array}).  Trainable variables get Adam slots; tensors alternate between two data shards."""
+    from nesti_net_amd import tf_ckpt
+    rng = np.random.RandomState(5)
+    tensors = {}
+    for layer, (wshape, cout, bn) in layers.items():
+        for nm in _tf112_names(layer, bn):
+            tensors[nm] = rng.randn(*(wshape if nm.endswith("/weights") else (cout,))).astype(np.float32)
+            if "/moments/" not in nm:
+                tensors[nm + "/Adam"] = rng.randn(*tensors[nm].shape).astype(np.float32)
+                tensors[nm + "/Adam_1"] = np.abs(rng.randn(*tensors[nm].shape)).astype(np.float32)
+    tensors["beta1_power"] = np.float32(0.9 ** 1000).reshape(())
+    tensors["beta2_power"] = np.float32(0.999 ** 1000).reshape(())
+    tensors["Variable"] = np.array(123456, dtype=np.int32).reshape(())          # the `batch` step counter, train_n_est_w_experts.py:128
+    for k, v in extra:
+        tensors[k] = v
+    prefix = str(tmp_path / "model.ckpt")
+    shards = [bytearray(), bytearray()]
+    tb = _HandTable(tf_ckpt.crc32c_py, tf_ckpt.mask_crc)
+    tb.add(b"", b"\x08\x02\x1a\x02\x08\x01")                   # BundleHeaderProto: num_shards = 2, version { producer = 1 }
+    for i, name in enumerate(sorted(tensors)):                # a table's keys are sorted bytewise
+        a = tensors[name]
+        sid = i % 2
+        raw = a.tobytes()
+        off = len(shards[sid])
+        shards[sid] += raw
+        dt = {np.dtype(np.float32): 1, np.dtype(np.int32): 3}[a.dtype]
+        tb.add(name.encode(), _pb_entry(dt, a.shape, sid, off, len(raw), tf_ckpt.mask_crc(tf_ckpt.crc32c_py(raw))))
+    open(prefix + ".index", "wb").write(tb.finish())
+    for sid in range(2):
+        open("%s.data-%05d-of-00002" % (prefix, sid), "wb").write(bytes(shards[sid]))
+    assert len(tb.index) >= 5, "the index must span several data blocks"
+    return prefix, tensors
+
+
+def test_tf112_shaped_checkpoint_assembled_by_hand(tmp_path):
+    """Several data blocks, restart points, prefix-compressed keys, Adam slots, the doubled EMA shadow names, two data
+    shards, multi-byte varints: the reader maps every graph variable -- and refuses the corrupted variants loudly."""
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import tf_ckpt
+    layers = {"inception1Expert_6_conv1": ((1, 1, 1, 60, 42), 42, True), "inception1Expert_6_conv2": ((3, 3, 3, 42, 21), 21, True),
+              "fc3Expert_6": ((128, 64), 64, True), "fc4Expert_6": ((64, 3), 3, False)}
+    prefix, tensors = _hand_checkpoint(tmp_path, layers)
+    ents = tf_ckpt.read_index(prefix + ".index")
+    assert sorted(ents) == sorted(tensors) and {e["shard_id"] for e in ents.values()} == {0, 1}
+    assert max(e["offset"] for e in ents.values()) > 16384                       # three-byte varints in the entry protos
+    raw = tf_ckpt.read_bundle(prefix)
+    for k, v in tensors.items():
+        assert np.array_equal(raw[k], v) and raw[k].dtype == v.dtype, k
+    expected = {}
+    for layer, (wshape, cout, bn) in layers.items():
+        expected[layer + "/weights"], expected[layer + "/biases"] = wshape, (cout,)
+        if bn:
+            for s in ("beta", "gamma", "mean", "var"):
+                expected["%s/bn/%s" % (layer, s)] = (cout,)
+    got = tf_ckpt.map_variables(raw, expected)
+    assert sorted(got) == sorted(expected)
+    for layer, (_, _, bn) in layers.items():
+        assert np.array_equal(got[layer + "/weights"], tensors[layer + "/weights"])
+        if bn:
+            sq = "%s/bn/%s/bn/moments/Squeeze" % (layer, layer)
+            assert np.array_equal(got[layer + "/bn/mean"], tensors[sq + "/ExponentialMovingAverage"])
+            assert np.array_equal(got[layer + "/bn/var"], tensors[sq + "_1/ExponentialMovingAverage"])
+            assert not np.array_equal(got[layer + "/bn/beta"], tensors[layer + "/bn/beta/Adam"])      # slots are not variables
+    # ---- refusals -----------------------------------------------------------------------------------------------------
+    d = str(tmp_path / "bad")
+    os.makedirs(d)
+    # (a) a third shadow under one bn scope (e.g. a second tower sharing the scope): mean / variance are ambiguous
+    p2, _ = _hand_checkpoint(tmp_path / "bad", layers, extra=[
+        ("fc3Expert_6/bn/fc3Expert_6/bn/moments/Squeeze_2/ExponentialMovingAverage", np.zeros(64, np.float32))])
+    with pytest.raises(KeyError, match="expected 2 EMA shadow"):
+        tf_ckpt.map_variables(tf_ckpt.read_bundle(p2), expected)
+    # (b) a shard is missing
+    os.remove(p2 + ".data-00001-of-00002")
+    with pytest.raises((FileNotFoundError, ValueError)):
+        tf_ckpt.read_bundle(p2)
+    # (c) one flipped bit inside the SECOND shard
+    s1 = bytearray(open(prefix + ".data-00001-of-00002", "rb").read())
+    s1[len(s1) // 2] ^= 0x10
+    open(prefix + ".data-00001-of-00002", "wb").write(bytes(s1))
+    with pytest.raises(ValueError, match="fails its crc32c"):
+        tf_ckpt.read_bundle(prefix)
+    # (d) one flipped bit inside a data block in the MIDDLE of the index
+    ix = bytearray(open(prefix + ".index", "rb").read())
+    ix[len(ix) // 3] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(ix))
+    with pytest.raises(ValueError, match="crc32c"):
+        tf_ckpt.read_index(prefix + ".index")
+
+
+def test_header_shard_count_is_honoured(tmp_path):
+    """Every tensor the graph needs may sit in shard 0 while the bundle still has two shards (the header says so): the data
+    file names carry the HEADER's shard count, not 1 + the largest shard id among the entries."""
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import tf_ckpt
+    tb = _HandTable(tf_ckpt.crc32c_py, tf_ckpt.mask_crc)
+    a = np.arange(6, dtype=np.float32)
+    tb.add(b"", b"\x08\x02\x1a\x02\x08\x01")                   # num_shards = 2
+    tb.add(b"fc/biases", _pb_entry(1, (6,), 0, 0, 24, tf_ckpt.mask_crc(tf_ckpt.crc32c_py(a.tobytes()))))
+    prefix = str(tmp_path / "m.ckpt")
+    open(prefix + ".index", "wb").write(tb.finish())
+    open(prefix + ".data-00000-of-00002", "wb").write(a.tobytes())
+    open(prefix + ".data-00001-of-00002", "wb").write(b"")
+    assert np.array_equal(tf_ckpt.read_bundle(prefix)["fc/biases"], a)
