@@ -203,6 +203,9 @@ int nesti_model_gate_error_import(nesti_model_t* m, const float* src_dev, int n,
  * 0 (the default) is NESTI_F16X3 proper.  Any other value does NOT hold the 1e-5 cosine tolerance on every query
  * (profiles/r05_expert_mix.txt); it exists to measure that.  Must not be changed while forward calls are in flight. */
 int nesti_model_set_expert_mix(nesti_model_t* m, int mask);
+/* The same switch for the gating net of a NESTI_F16X3 / NESTI_BF16X3 model (non-cascade nesti_gate_forward / nesti_forward):
+ * on != 0 runs ALL its k^3 tap layers at 8^3 / 4^3 single-product, the 1x1x1 / FC layers stay three-product ("medium" gate). */
+int nesti_model_set_gate_mix(nesti_model_t* m, int on);
 
 /* Workspace of ONE tower for `batch` queries, from the configuration alone (no device needed): tower = -1 the gating
  * net, 0..E-1 an expert.  dtype as nesti_model_create (NESTI_F16X3C: the gate figure is the f16 filter's). */

@@ -446,6 +446,7 @@ struct nesti_model {
   // and writes its outputs as pairs again
   std::vector<nesti::PackedLayer> packed_mix;
   int expert_mix = 0;
+  int gate_mix = 0;          // EXPERIMENT (nesti_model_set_gate_mix): the f16x3 gating passes run their tap layers single-product
   float tau = 0.25f;
   unsigned long long* cstat = nullptr;
   ~nesti_model() {
@@ -770,6 +771,8 @@ int conv_category(const LayerDesc& d, const PackedLayer& pl) {
   return pl.n_taps > 1 ? NESTI_PROF_TAPS : NESTI_PROF_ONE_BY_ONE;
 }
 
+constexpr int kGateMixBit = 8;   // packed_mix entries of the gating net: RunCtx::mix bit 8 switches all of them
+
 struct RunCtx {
   const nesti_model* m;
   int NB;                        // capacity (points)
@@ -936,7 +939,7 @@ int gate_cascade(const nesti_model* m, const void* X0, int B, unsigned char* ws,
 
 int gate_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_ws, size_t tower_bytes_,
               float* probs, int32_t* expert, int32_t* counts, int32_t* lists, hipStream_t stream) {
-  RunCtx rc{m, B, nullptr, nullptr, stream};
+  RunCtx rc{m, B, nullptr, nullptr, stream, false, m->gate_mix ? (1 << kGateMixBit) : 0};
   float* logits = nullptr;
   prof_phase(NESTI_PHASE_GATE);
   if (run_tower(rc, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
@@ -1080,6 +1083,14 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
   if (act_planes(dtype) > 1 && cfg->arch == NESTI_ARCH_EXPERTS && cfg->grid_n == 8) {
     m->packed_mix.resize(m->graph.layers.size());
     const int plain = kernel_dtype(dtype);
+    // the gating net's tap layers (conv8n_kernel / conv4n_kernel): one switch for all of them, bit kGateMixBit
+    for (const Op& op : m->graph.gate.ops) {
+      if (op.kind != Op::CONV) continue;
+      const LayerDesc& d = m->graph.layers[op.layer];
+      if (!use_conv8(d) && !(use_conv4(d, plain) && m->packed[op.layer].kind == 3)) continue;
+      if (pack_layer(d, tt, plain, &m->packed_mix[op.layer])) return 1;
+      m->packed_mix[op.layer].mix_bit = kGateMixBit;
+    }
     for (const Tower& T : m->graph.experts)
       for (const Op& op : T.ops) {
         if (op.kind != Op::CONV) continue;
@@ -1119,6 +1130,13 @@ int nesti_model_set_expert_mix(nesti_model_t* m, int mask) {
   if (mask && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_expert_mix: pair-mode experts_n_est models (8^3 grid) only");
   if (mask < 0 || mask >= (1 << 6)) NESTI_FAIL("nesti_model_set_expert_mix: mask has six bits");
   m->expert_mix = mask;
+  return 0;
+}
+
+int nesti_model_set_gate_mix(nesti_model_t* m, int on) {
+  if (!m) NESTI_FAIL("nesti_model_set_gate_mix: null model");
+  if (on && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_gate_mix: pair-mode experts_n_est models (8^3 grid) only");
+  m->gate_mix = on ? 1 : 0;
   return 0;
 }
 

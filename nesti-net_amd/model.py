@@ -132,6 +132,10 @@ class NestiNet:
         """EXPERIMENT: which expert tap layers run a single 16-bit product (``nesti_model_set_expert_mix``; 0 = none)."""
         _lib.check(self.lib.nesti_model_set_expert_mix(self._handle, int(mask)), "nesti_model_set_expert_mix")
 
+    def set_gate_mix(self, on):
+        """EXPERIMENT: the (non-cascade) pair-mode gating net with single-product tap layers (``nesti_model_set_gate_mix``)."""
+        _lib.check(self.lib.nesti_model_set_gate_mix(self._handle, int(bool(on))), "nesti_model_set_gate_mix")
+
     def export_gate_error(self, dst, stream=None):
         """Write this model's ``max_margin_err`` into the one-element f32 device tensor ``dst`` (no synchronisation)."""
         with torch.cuda.device(self.device):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerates the judged profile artefacts on the GPU box into gpurun_out/profiles/ (copy them into profiles/r04_* afterwards):
+# Regenerates the judged profile artefacts on the GPU box into gpurun_out/profiles/ (copy them into profiles/r05_* afterwards):
 #   bench_n1.json               python3 bench.py (default command: f16x3c, calibrated gate, two streams x 50 176 queries for the
 #                               headline + a single-stream pass of batch 100 000 for the roofline object)
 #   bench_steps20.json          the driver's form of the command (--steps 20 --warmup 5)
