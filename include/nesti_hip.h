@@ -197,11 +197,12 @@ int nesti_model_cascade_stats(const nesti_model_t* m, nesti_cascade_stats_t* out
 int nesti_model_gate_error_export(const nesti_model_t* m, float* dst_dev, void* stream);
 int nesti_model_gate_error_import(nesti_model_t* m, const float* src_dev, int n, void* stream);
 
-/* EXPERIMENT (pair-mode experts_n_est models, 8^3 grid; no reference counterpart): which of the experts' k^3 tap layers run ONE
+/* EXPERIMENT (pair-mode experts_n_est models, 8^3 grid, created after nesti_experiment_mix_enable(1); no reference counterpart): which of the experts' k^3 tap layers run ONE
  * 16-bit product (hi * W_hi, reading only the hi planes of their pair-layout input, writing pairs again) instead of three.
  * Bits: 0 / 1 = inception1 conv2 (3^3) / conv3 (5^3), 2 / 3 = inception2 conv2 / conv3, 4 / 5 = inception4 conv2 (2^3) / conv3 (4^3).
  * 0 (the default) is NESTI_F16X3 proper.  Any other value does NOT hold the 1e-5 cosine tolerance on every query
  * (profiles/r05_expert_mix.txt); it exists to measure that.  Must not be changed while forward calls are in flight. */
+int nesti_experiment_mix_enable(int on); /* process-wide, BEFORE nesti_model_create: pack the extra single-product copies (default off) */
 int nesti_model_set_expert_mix(nesti_model_t* m, int mask);
 /* The same switch for the gating net of a NESTI_F16X3 / NESTI_BF16X3 model (non-cascade nesti_gate_forward / nesti_forward):
  * on != 0 runs ALL its k^3 tap layers at 8^3 / 4^3 single-product, the 1x1x1 / FC layers stay three-product ("medium" gate). */

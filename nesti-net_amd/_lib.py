@@ -65,6 +65,7 @@ SIGNATURES = {
     "nesti_model_cascade_stats": (_i, [_vp, ctypes.POINTER(CCascadeStats), _i, _vp]),
     "nesti_model_gate_error_export": (_i, [_vp, _vp, _vp]),
     "nesti_model_gate_error_import": (_i, [_vp, _vp, _i, _vp]),
+    "nesti_experiment_mix_enable": (_i, [_i]),
     "nesti_model_set_expert_mix": (_i, [_vp, _i]),
     "nesti_model_set_gate_mix": (_i, [_vp, _i]),
     "nesti_tower_workspace_bytes": (_sz, [_cfgp, _i, _i, _i]),

@@ -22,6 +22,9 @@ namespace nesti {
 // errors
 // ------------------------------------------------------------------------------------------
 static thread_local std::string g_error;
+// nesti_experiment_mix_enable: models created while this is set also pack their tap layers for the single-product experiments
+// (nesti_model_set_expert_mix / _gate_mix); off by default, so product models neither pay the packing time nor hold the copies
+static bool g_experiment_mix = false;
 void set_error(const std::string& msg) { g_error = msg; }
 
 // ------------------------------------------------------------------------------------------
@@ -1080,7 +1083,7 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
   bool any_conv8 = false;
   for (const PackedLayer& pl : m->packed) any_conv8 = any_conv8 || pl.kind == 2;
   if (any_conv8 && conv8_selftest()) return 1;
-  if (act_planes(dtype) > 1 && cfg->arch == NESTI_ARCH_EXPERTS && cfg->grid_n == 8) {
+  if (g_experiment_mix && act_planes(dtype) > 1 && cfg->arch == NESTI_ARCH_EXPERTS && cfg->grid_n == 8) {
     m->packed_mix.resize(m->graph.layers.size());
     const int plain = kernel_dtype(dtype);
     // the gating net's tap layers (conv8n_kernel / conv4n_kernel): one switch for all of them, bit kGateMixBit
@@ -1125,9 +1128,14 @@ int nesti_model_set_gate_margin(nesti_model_t* m, float tau) {
   return 0;
 }
 
+int nesti_experiment_mix_enable(int on) {
+  g_experiment_mix = on != 0;
+  return 0;
+}
+
 int nesti_model_set_expert_mix(nesti_model_t* m, int mask) {
   if (!m) NESTI_FAIL("nesti_model_set_expert_mix: null model");
-  if (mask && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_expert_mix: pair-mode experts_n_est models (8^3 grid) only");
+  if (mask && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_expert_mix: pair-mode experts_n_est models (8^3 grid) created after nesti_experiment_mix_enable(1) only");
   if (mask < 0 || mask >= (1 << 6)) NESTI_FAIL("nesti_model_set_expert_mix: mask has six bits");
   m->expert_mix = mask;
   return 0;
@@ -1135,7 +1143,7 @@ int nesti_model_set_expert_mix(nesti_model_t* m, int mask) {
 
 int nesti_model_set_gate_mix(nesti_model_t* m, int on) {
   if (!m) NESTI_FAIL("nesti_model_set_gate_mix: null model");
-  if (on && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_gate_mix: pair-mode experts_n_est models (8^3 grid) only");
+  if (on && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_gate_mix: pair-mode experts_n_est models (8^3 grid) created after nesti_experiment_mix_enable(1) only");
   m->gate_mix = on ? 1 : 0;
   return 0;
 }

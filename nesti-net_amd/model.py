@@ -265,9 +265,60 @@ def placeholder_inputs(batch_size, n_points, gmm, radius, device="cuda:0"):
             torch.zeros((batch_size, n_rads), dtype=torch.int32, device=dev))
 
 
-def get_model(net: NestiNet, points, original_n_points):
+def get_model(*args, net=None, **kwargs):
     """``models/experts_n_est.py:40-108`` return contract:
-    (experts_prob [E,B], n_est [E,B,3], MuPS [B,R,R,R,20*S])."""
+    (experts_prob [E,B], n_est [E,B,3], MuPS [B,R,R,R,20*S]).
+
+    Two call forms.  The reference's own argument list (``models/experts_n_est.py:40``) plus ONE keyword-only argument
+    carrying the restored variables -- a TF1 graph finds its weights in the session, a library call needs the handle::
+
+        get_model(points, w, mu, sigma, is_training, radius, bn_decay=None, weight_decay=0.005,
+                  original_n_points=None, n_experts=2, expert_dict=None, *, net=<NestiNet>)
+
+    ``w`` / ``mu`` / ``sigma`` must be the Gaussian grid the model was built for (``get_3d_grid_gmm``), ``radius`` /
+    ``n_experts`` / ``expert_dict`` must agree with ``net.cfg`` and ``is_training`` must be False (inference only); a
+    mismatch raises instead of being ignored.  ``bn_decay`` and ``weight_decay`` only matter in training and are accepted
+    for signature compatibility.  The short form ``get_model(net, points, original_n_points)`` is what the rest of this
+    package uses."""
+    if args and isinstance(args[0], NestiNet):
+        if net is not None or kwargs or len(args) != 3:
+            raise TypeError("short form: get_model(net, points, original_n_points)")
+        net, points, original_n_points = args
+    else:
+        names = ("points", "w", "mu", "sigma", "is_training", "radius", "bn_decay", "weight_decay", "original_n_points",
+                 "n_experts", "expert_dict")
+        if len(args) > len(names):
+            raise TypeError("get_model takes at most %d positional arguments" % len(names))
+        a = dict(zip(names, args))
+        for k, v in kwargs.items():
+            if k not in names or k in a:
+                raise TypeError("get_model: unexpected or repeated argument %r" % k)
+            a[k] = v
+        for k in names[:6]:
+            if k not in a:
+                raise TypeError("get_model: missing argument %r (models/experts_n_est.py:40)" % k)
+        if net is None:
+            raise TypeError("get_model: pass the restored model as net=<NestiNet> (the reference finds its variables in the session)")
+        cfg = net.cfg
+        if bool(a["is_training"]):
+            raise ValueError("get_model: inference only (is_training must be False)")
+        if len(a["radius"]) != cfg.n_scales or any(abs(float(x) - float(y)) > 1e-12 for x, y in zip(a["radius"], cfg.patch_radius)):
+            raise ValueError("get_model: radius %s differs from the model's %s" % (list(a["radius"]), list(cfg.patch_radius)))
+        gw, gmu, gsg = get_3d_grid_gmm((cfg.n_gaussians,) * 3, cfg.gmm_variance)
+        for name, got, want in (("w", a["w"], gw), ("mu", a["mu"], gmu), ("sigma", a["sigma"], gsg)):
+            got = got.detach().cpu().numpy() if hasattr(got, "detach") else np.asarray(got)
+            if got.shape != want.shape or not np.allclose(got, want, rtol=0, atol=1e-6):
+                raise ValueError("get_model: %s is not the %d^3 Gaussian grid (variance %g) this model was built for"
+                                 % (name, cfg.n_gaussians, cfg.gmm_variance))
+        if a.get("expert_dict") is not None:
+            ed = {int(k): [int(x) for x in v] for k, v in dict(a["expert_dict"]).items()}
+            if ed != {int(k): list(v) for k, v in cfg.expert_dict.items()}:
+                raise ValueError("get_model: expert_dict differs from the model's")
+            if int(a.get("n_experts", len(ed))) != cfg.n_experts:
+                raise ValueError("get_model: n_experts differs from the model's %d" % cfg.n_experts)
+        if a.get("original_n_points") is None:
+            raise ValueError("get_model: original_n_points (the n_effective_points placeholder) is required")
+        points, original_n_points = a["points"], a["original_n_points"]
     mups = net.mups(points, original_n_points)
     probs, _ = net.gate(mups)
     n_est = net.experts(mups, None)

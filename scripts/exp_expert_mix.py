@@ -32,6 +32,8 @@ MASKS = [(0b001000, "i2 conv3 (5^3 256->128)"), (0b000100, "i2 conv2 (3^3)"), (0
          (0b001010, "both 5^3 at 8^3"), (0b001111, "all taps at 8^3"), (0b111111, "all taps at 8^3 and 4^3")]
 TARGETS = (2.5e-6, 5e-6, 1e-5)
 
+from nesti_net_amd import _lib  # noqa: E402
+_lib.load().nesti_experiment_mix_enable(1)      # models created below also carry the single-product copies of their tap layers
 dev = torch.device("cuda:0")
 cfg = NestiConfig()
 N = int(os.environ.get("MIX_POINTS", "100000"))

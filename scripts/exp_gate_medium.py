@@ -21,6 +21,8 @@ from nesti_net_amd.config import NestiConfig  # noqa: E402
 from nesti_net_amd.model import NestiNet  # noqa: E402
 from nesti_net_amd.provider import CloudPatches  # noqa: E402
 
+from nesti_net_amd import _lib  # noqa: E402
+_lib.load().nesti_experiment_mix_enable(1)      # models created below also carry the single-product copies of their tap layers
 dev = torch.device("cuda:0")
 cfg = NestiConfig()
 N = int(os.environ.get("MED_POINTS", "100000"))

@@ -357,6 +357,24 @@ def test_3_gaussian_grid_model_matches_oracle(gpu_device):
     assert np.all(1 - _cos(normals.cpu().numpy(), ref["normals"].numpy()) < COS_TOL_F32)
     pr, ne, mu = get_model(net, p_d, n_d)
     assert mu.shape == (B, 3, 3, 3, 60) and pr.shape == (7, B) and ne.shape == (7, B, 3)
+    # the reference's own argument list (models/experts_n_est.py:40) + the restored model as the one keyword-only argument
+    from nesti_net_amd.model import get_3d_grid_gmm, placeholder_inputs
+    gw, gmu, gsg = get_3d_grid_gmm((3, 3, 3), 0.111)
+    points_pl, normal_pl, w_pl, mu_pl, sigma_pl, n_eff_pl = placeholder_inputs(B, cfg.num_point, (gw, gmu, gsg), cfg.patch_radius,
+                                                                              device=gpu_device)
+    points_pl.copy_(p_d)
+    n_eff_pl.copy_(n_d)
+    pr2_, ne2_, mu2_ = get_model(points_pl, w_pl, mu_pl, sigma_pl, False, cfg.patch_radius, original_n_points=n_eff_pl,
+                                 n_experts=cfg.n_experts, expert_dict=cfg.expert_dict, net=net)
+    assert torch.equal(pr2_, pr) and torch.equal(ne2_, ne) and torch.equal(mu2_, mu)
+    with pytest.raises(ValueError, match="Gaussian grid"):
+        get_model(points_pl, w_pl, mu_pl + 0.5, sigma_pl, False, cfg.patch_radius, original_n_points=n_eff_pl, net=net)
+    with pytest.raises(ValueError, match="inference only"):
+        get_model(points_pl, w_pl, mu_pl, sigma_pl, True, cfg.patch_radius, original_n_points=n_eff_pl, net=net)
+    with pytest.raises(ValueError, match="radius"):
+        get_model(points_pl, w_pl, mu_pl, sigma_pl, False, [0.1, 0.2, 0.3], original_n_points=n_eff_pl, net=net)
+    with pytest.raises(TypeError, match="net="):
+        get_model(points_pl, w_pl, mu_pl, sigma_pl, False, cfg.patch_radius, original_n_points=n_eff_pl)
     # production dtypes
     for dt, tol in (("bf16", 2e-3), ("f16", 5e-5)):
         n16 = NestiNet(cfg, W, dtype=dt, device=gpu_device, max_batch=B)
