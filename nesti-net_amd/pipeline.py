@@ -150,20 +150,42 @@ class NormalEstimator:
         return normals, expert, probs
 
     def _run_reference_order(self, cloud, first, count, normals, expert, probs, single_tower):
-        """Patch rows [first, first + count) with the reference's own subsample (host), then the usual forward pass."""
+        """Patch rows [first, first + count) with the reference's own subsample (host), then the usual forward pass.  The host
+        pass of batch k + 1 (scipy ball query + the replayed random stream, ``refsample.py``) runs in a worker thread while batch
+        k is uploaded and goes through the GPU; the sampler is only ever called from that one thread, batch after batch, so the
+        shared random stream stays in the reference's visiting order."""
+        import queue
+        import threading
         if getattr(cloud, "_ref_tree", None) is None:
             cloud._ref_tree = self._ref.build_tree(cloud.host_pts)
         S, P = self.cfg.n_scales, self.cfg.num_point
-        done = 0
-        while done < count:
-            take = min(self.batch, count - done)
-            rows = np.arange(first + done, first + done + take)
-            centers = cloud.pidx[first + done:first + done + take].cpu().numpy() if cloud.pidx is not None else rows
-            p, n = self._ref.patches(cloud.host_pts, cloud._ref_tree, centers, cloud.r_abs, P)
+        pidx_host = cloud.pidx[first:first + count].cpu().numpy() if cloud.pidx is not None else None
+        spans = [(done, min(self.batch, count - done)) for done in range(0, count, self.batch)]
+        ready = queue.Queue()
+        free = threading.Semaphore(2)           # the sampler alternates between TWO buffers: a batch may only be produced once
+                                                # the batch before the previous one has been uploaded
+
+        def produce():
+            try:
+                for done, take in spans:
+                    free.acquire()
+                    centers = pidx_host[done:done + take] if pidx_host is not None else np.arange(first + done, first + done + take)
+                    ready.put(self._ref.patches(cloud.host_pts, cloud._ref_tree, centers, cloud.r_abs, P))
+            except BaseException as e:      # noqa: BLE001 -- hand the failure to the consumer instead of dying silently
+                ready.put(e)
+
+        worker = threading.Thread(target=produce, daemon=True)
+        worker.start()
+        for done, take in spans:
+            item = ready.get()
+            if isinstance(item, BaseException):
+                raise item
+            p, n = item
             sl = slice(done, done + take)
-            self.net.forward(torch.from_numpy(p).to(self.device), torch.from_numpy(n).to(self.device).view(take, S),
-                             out=(normals[sl], expert[sl], probs[sl]))
-            done += take
+            p_d, n_d = torch.from_numpy(p).to(self.device), torch.from_numpy(n).to(self.device).view(take, S)   # synchronous copies
+            free.release()                      # the host buffer may be refilled
+            self.net.forward(p_d, n_d, out=(normals[sl], expert[sl], probs[sl]))
+        worker.join()
         if single_tower:
             return normals, None, None
         return normals, expert, probs

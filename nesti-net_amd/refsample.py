@@ -44,8 +44,8 @@ class ReferencePatchSampler:
 
     def patches(self, pts, tree, center_inds, r_abs, P):
         """``pts`` [N,3] float32, ``center_inds`` [M] point indices (the shape's .pidx rows or a range), ``r_abs`` the
-        absolute radii (Python floats, :282) -> points [M, S*P, 3] float32, n_eff [M, S] int32.  ``points`` is a buffer the
-        sampler reuses for the next call with the same M: copy (or upload) it before asking for the next batch.
+        absolute radii (Python floats, :282) -> points [M, S*P, 3] float32, n_eff [M, S] int32.  ``points`` is one of two
+        buffers the sampler alternates between: it stays valid until the call AFTER the next one.
 
         Batched: ONE ``query_ball_point`` per scale for all M centres (all cores; ``return_sorted=False`` keeps cKDTree's
         traversal order, which is what a single-point query returns and what the reference subsamples), then the shared
@@ -59,10 +59,14 @@ class ReferencePatchSampler:
         n_eff = np.zeros((M, S), np.int32)
         if M == 0:
             return np.zeros((0, S * P, 3), np.float32), n_eff
-        if (M, S, P) not in self._bufs:
-            self._bufs = {(M, S, P): (np.empty((M, S * P, 3), np.float32), np.empty((M, P), np.int32))}
-        points, idx = self._bufs[(M, S, P)]      # every element is overwritten below (:298's zero rows included); the caller
-                                                 # must be done with the previous batch's tensor, see NormalEstimator
+        # two alternating buffer sets: the batch handed out by the PREVIOUS call stays valid while this one is being filled
+        # (NormalEstimator overlaps the host pass of batch k + 1 with the upload + GPU forward of batch k)
+        self._flip = 1 - getattr(self, "_flip", 1)
+        key = (M, S, P, self._flip)
+        if key not in self._bufs:
+            self._bufs = {k: v for k, v in self._bufs.items() if k[:3] == (M, S, P)}
+            self._bufs[key] = (np.empty((M, S * P, 3), np.float32), np.empty((M, P), np.int32))
+        points, idx = self._bufs[key]            # every element is overwritten below (:298's zero rows included)
         centers = pts[center_inds]
         balls = [tree.query_ball_point(centers, rad, return_sorted=False, workers=-1) for rad in r_abs]     # :304, all centres
         sizes = np.stack([np.fromiter(map(len, balls[s]), dtype=np.int64, count=M) for s in range(S)], axis=1)

@@ -220,3 +220,59 @@ def test_cascade_is_for_the_gated_model_only(gpu_device):
         net.set_gate_margin(0.1)
     with pytest.raises(_lib.NestiError):
         net.cascade_stats()
+
+
+def test_gate_error_export_import_and_mix_switches(case, gpu_device):
+    """The multi-GPU plumbing of the gate's error counter on real kernels (nesti_model_gate_error_export / _import: what rides in
+    the spare row of dist.py's all-gather), and the experimental single-product switches: off by default (a model only packs the
+    extra copies after nesti_experiment_mix_enable(1)), bit-identical when enabled but switched off, and a measurably different
+    -- yet close -- result when a tap layer runs one product instead of three."""
+    from nesti_net_amd import _lib
+    from nesti_net_amd.model import NestiNet
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
+    net.set_gate_margin(0.05)
+    net.cascade_stats(reset=True)
+    net(points, n_eff)
+    st = net.cascade_stats()
+    buf = torch.zeros(4, dtype=torch.float32, device=gpu_device)
+    net.export_gate_error(buf[1:2])
+    torch.cuda.synchronize()
+    assert buf[1].item() == pytest.approx(st["max_margin_err"], rel=0, abs=0) and buf[0].item() == 0.0
+    # another rank has measured a larger error: this model's threshold follows; NaN / inf / negative entries are ignored
+    others = torch.tensor([0.01, float("nan"), 2.0 * st["max_margin_err"], float("inf"), -1.0], dtype=torch.float32, device=gpu_device)
+    net.import_gate_error(others)
+    st2 = net.cascade_stats()
+    assert st2["max_margin_err"] == pytest.approx(2.0 * st["max_margin_err"], rel=1e-6)
+    assert st2["tau_eff"] == pytest.approx(max(st2["tau"], 1.5 * st2["max_margin_err"]), rel=1e-6)
+    net.import_gate_error(torch.tensor([1e-6], dtype=torch.float32, device=gpu_device))      # a smaller value changes nothing
+    assert net.cascade_stats()["max_margin_err"] == st2["max_margin_err"]
+    with pytest.raises(_lib.NestiError, match="nesti_experiment_mix_enable"):
+        net.set_expert_mix(0b001000)                                      # this model was created without the extra copies
+    del net
+    # ---- the experiment switches -----------------------------------------------------------------------------------------
+    lib = _lib.load()
+    lib.nesti_experiment_mix_enable(1)
+    try:
+        x3 = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=B)
+    finally:
+        lib.nesti_experiment_mix_enable(0)
+    mups = x3.mups(points, n_eff)
+    base = x3.experts(mups, ref[1]).clone()
+    assert torch.equal(base, ref[0])                                      # enabled but switched off: f16x3 proper
+    x3.set_expert_mix(0b001000)                                           # inception2's 5^3 layer single-product
+    mixed = x3.experts(mups, ref[1]).clone()
+    x3.set_expert_mix(0)
+    assert torch.equal(x3.experts(mups, ref[1]), base)
+    a, b = mixed.double().cpu().numpy(), base.double().cpu().numpy()
+    omc = 1 - (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    print("expert mix 001000: 1-cos p50 %.3g max %.3g" % (np.median(omc), omc.max()))
+    assert not np.array_equal(a, b) and np.median(omc) < 1e-6 and omc.max() < 5e-2
+    pg, eg = x3.gate(mups)
+    assert torch.equal(pg, ref[2])
+    x3.set_gate_mix(1)
+    pm, em = x3.gate(mups)
+    x3.set_gate_mix(0)
+    assert not torch.equal(pm, pg) and (pm - pg).abs().max().item() < 0.05 and (em != eg).float().mean().item() < 0.02
+    with pytest.raises(_lib.NestiError, match="six bits"):
+        x3.set_expert_mix(1 << 6)
