@@ -51,8 +51,16 @@ constexpr int kPoolStride = 272;              // bytes per row of the fp32 [512]
 //   8^3: tile = x 0..7 x y pair yp x z pair s, s = 2*(wave>>2) + mi, yp = (c - s) & 3, c = wave & 3;
 //   4^3: tile = the x-line (y, z) of all 8 points of the workgroup, z = s, y = (c - s) & 3 -- both y and z skip at
 //        single-voxel granularity (issued/nominal 0.5625 for the 4^3 taps; 0.66 with (4x,2y) half-planes of 4 points).
+//   2^3 (remap == 2, round 5): tile = ONE voxel of 32 of the workgroup's 64 points, so a padding tap kills whole tiles in all three
+//        axes (issued / nominal 0.42 for k = 2, 0.30 for the 27 kept taps of k = 4, instead of 1).  The chunk sits in LDS in
+//        (voxel block, point) order -- block b = rows [64 b, 64 b + 64) holds voxel vox2(b) of the 64 points -- so a tile is 32
+//        CONSECUTIVE LDS rows (natural swizzle, conflict-free) and wave w owns block w; vox2 puts complementary voxels v and 7 - v
+//        on the two waves of a SIMD: whatever axes a tap shifts along, each SIMD keeps (nearly) the same number of live tiles.
+//        tile_row still returns the row's offset in GLOBAL order (what the epilogues store by).
+__device__ __forceinline__ int vox2(int b) { return b < 4 ? b : 11 - b; }      // block <-> voxel, its own inverse
 __device__ __forceinline__ int tile_row(int remap, int log2S, int wave, int mi, int l) {
   if (!remap) return wave * 64 + mi * 32 + l;
+  if (remap == 2) return ((mi * 32 + l) << 3) + vox2(wave);
   const int c = wave & 3, s = 2 * (wave >> 2) + mi;
   const int q = (c - s) & 3;
   if (log2S == 3) return ((2 * s + (l >> 4)) << 6) + ((2 * q + ((l >> 3) & 1)) << 3) + (l & 7);
@@ -115,7 +123,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   for (int j = 0; j < 8; ++j) {
     const int row_l = (wave * 8 + j) * 8 + (lane >> 3);
     const int slot = (lane & 7) ^ swz_key(row_l);   // inverse swizzle on the SOURCE
-    const long long gr = r0 + row_l;
+    // remap == 2: LDS row (block b, point pt) <- global row 8 pt + vox2(b)
+    const long long gr = r0 + (remap == 2 ? ((row_l & 63) << 3) + vox2(row_l >> 6) : row_l);
     if (gr < total_rows) {
       long long pt = gr >> log2V;
       const long long vox = gr & (V - 1);
@@ -151,8 +160,9 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   int rz[2], ry[2], rx[2], rrow[2];
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
-    rrow[mi] = tile_row(remap, log2S, wave, mi, lane & 31);
-    const int vox = rrow[mi] & (V - 1);
+    // the LDS row the lane's fragment row lives in (remap == 2: LDS order differs from global order, see tile_row)
+    rrow[mi] = remap == 2 ? wave * 64 + mi * 32 + (lane & 31) : tile_row(remap, log2S, wave, mi, lane & 31);
+    const int vox = remap == 2 ? vox2(wave) : rrow[mi] & (V - 1);
     rz[mi] = vox >> (2 * log2S);
     ry[mi] = (vox >> log2S) & (S - 1);
     rx[mi] = vox & (S - 1);
@@ -301,7 +311,8 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
 #pragma unroll
           for (int mi = 0; mi < 2; ++mi) {
             const bool ok = ((unsigned)(rz[mi] + dz) < Sb) & ((unsigned)(ry[mi] + dy) < Sb) & ((unsigned)(rx[mi] + dx) < Sb);
-            const int srow = rrow[mi] + shift;
+            // remap == 2: the source voxel's block instead of a linear row shift (ok is wave-uniform there)
+            const int srow = remap == 2 ? rrow[mi] + ((vox2((vox2(wave) + shift) & 7) - wave) << 6) : rrow[mi] + shift;
             a_addr[mi] = ok ? srow * kRowBytes : kZeroOff;   // padding tap -> the zero row
             a_sw[mi] = ok ? swz_key(srow) : 0;
             live[mi] = __ballot(ok) != 0ull;                 // an all-padding tile issues no MFMAs

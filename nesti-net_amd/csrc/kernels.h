@@ -51,7 +51,8 @@ struct ConvParams {
                        // out_coff2 -- the block is followed by max_pool3d and nobody reads conv4 at full resolution
   // k^3-tap layers: 1 = the 16 32-row MFMA tiles of a workgroup are (8x,2y,2z) blocks (8^3) / x-lines of the
   // 8 points (4^3), dealt to the 4 SIMDs as a Latin square so that the tiles a padding tap skips are spread evenly
-  // over the matrix pipes (conv.hip: tile_row).  0 = tile t holds rows [32t, 32t+32).
+  // over the matrix pipes (conv.hip: tile_row).  0 = tile t holds rows [32t, 32t+32).  2 (2^3 volumes) = a tile is ONE voxel of
+  // 32 points and the chunk sits in LDS in (voxel, point) order: padding skips whole tiles in all three axes.
   int remap;
   // NESTI_BF16X3 / NESTI_F16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (two planes per
   // 64-channel group); out_coff / out_coff2 stay logical and every 16-bit store goes through split_col + two planes.

@@ -764,7 +764,9 @@ size_t tower_bytes(const Tower& T, int NB, int dtype) { return place_tower(T, NB
 // fall entirely on padding -- 5^3 taps at 8^3 (|d| = 2 clears a y/z pair) and every multi-tap layer at 4^3.  3^3 at
 // 8^3 only ever clears single planes, which no 32-row tile shape can balance over four SIMDs.
 int conv_remap(int k, int log2S, int n_taps) {
-  if (n_taps <= 1 || (log2S != 2 && log2S != 3)) return 0;
+  if (n_taps <= 1) return 0;
+  if (log2S == 1) return 2;              // 2^3: single-voxel tiles of 32 points (conv.hip: remap == 2)
+  if (log2S != 2 && log2S != 3) return 0;
   return (log2S == 2 || k >= 4) ? 1 : 0;
 }
 
@@ -1444,11 +1446,12 @@ int nesti_model_macs(const nesti_model_t* m, int tower, int kind, double* nomina
     // (conv4n_kernel's tile is a single voxel: it issues exactly the taps that land inside the volume)
     double tap_sum = pl.n_taps;
     const int Si = 1 << d.log2S;
-    if (pl.n_taps > 1 && (pl.kind >= 1 || (d.log2S == 2 && conv_remap(d.k, d.log2S, pl.n_taps)))) {
+    const bool voxel_tiles = pl.kind == 3 || (pl.kind == 0 && !d.s_real && conv_remap(d.k, d.log2S, pl.n_taps) == 2);
+    if (pl.n_taps > 1 && (pl.kind >= 1 || voxel_tiles || (d.log2S == 2 && conv_remap(d.k, d.log2S, pl.n_taps)))) {
       tap_sum = 0;
       for (int t = 0; t < pl.n_taps; ++t)
         tap_sum += (double)std::max(0, S - abs(pl.tap[t][0])) * std::max(0, S - abs(pl.tap[t][1])) / ((double)Si * Si) *
-                   (pl.kind == 3 ? (double)std::max(0, S - abs(pl.tap[t][2])) / Si : 1.0);
+                   (voxel_tiles ? (double)std::max(0, S - abs(pl.tap[t][2])) / Si : 1.0);
     }
     iss += (double)(1 << (3 * d.log2S)) * tap_sum * d.Cin_p * d.Cout_p;
   }
