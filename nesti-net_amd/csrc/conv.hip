@@ -84,8 +84,9 @@ struct SwzKey {
 // chunk is 32 channels -- the LDS row [hi k0..31 | lo k0..31], staged from the two planes, the weight row [W_hi | W_lo] --
 // and one set of fragment reads feeds three MFMAs (lo * W_hi, hi * W_hi, hi * W_lo): 1.5x the MFMAs per LDS byte, per
 // staged byte and per barrier of the plain kernel.
+// one (M tile, N tile) of the layer; `bid` is the position in the XCD-aware block order (blockIdx.x of a one-tile-per-workgroup launch)
 template <int DT, int TN, bool KPIPE, bool X3>
-__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsigned bid, const int tid_in) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NI = TN / 32;
   constexpr int kBTile = TN * kRowBytes;
@@ -97,12 +98,12 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   constexpr int kNB = KPIPE ? 2 : 4;              // weight-tile slots (general variant: 2 groups of 2 taps)
   constexpr int kZeroOff = kNA * kABytes + kNB * kBTile;   // all-zero 128-B row (general variant only)
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = tid_in, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // XCD-aware block -> tile map: the 8 blocks of a dispatch group land on the 8 XCDs; each XCD
   // keeps its M tile and walks the N tiles, so the staged input stays in that XCD's L2.
-  const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
+  const int xcd = bid & 7, grp = bid >> 3;
   const int n_tile = grp % p.n_tiles;
   const int m_tile = (grp / p.n_tiles) * 8 + xcd;
   if (m_tile >= p.m_tiles) return;
@@ -622,6 +623,31 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
   }
 }
 
+template <int DT, int TN, bool KPIPE, bool X3, bool WALK>
+__global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p) {
+  if constexpr (!WALK) {
+    conv_igemm_tile<DT, TN, KPIPE, X3>(p, blockIdx.x, threadIdx.x);
+  } else {
+    // walking launch (kernels.h: ConvParams::walk), a kernel of its own so that the one-tile-per-workgroup kernel keeps its register
+    // allocation: only the tiles below the live row count; the thread index is laundered per trip, otherwise hipcc hoists every
+    // per-lane address out of the tile loop and spills
+    unsigned n_blocks;
+    {
+      int npts = p.npoints;
+      if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
+      const long long rows = (long long)npts << (3 * p.log2S);
+      const unsigned m_live = (unsigned)((rows + kTileM - 1) / kTileM);
+        n_blocks = (m_live + 7) / 8 * 8 * (unsigned)p.n_tiles;
+    }
+    for (unsigned bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+      if (bid != blockIdx.x) __syncthreads();    // the previous tile's epilogue is done with the LDS
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      conv_igemm_tile<DT, TN, KPIPE, X3>(p, bid, tid);
+    }
+  }
+}
+
 template <int TN, bool KPIPE>
 constexpr size_t lds_bytes() {
   constexpr size_t kPoolTile = (size_t)kTileM * kPoolStride + 16;         // fp32 pooling tile of the epilogues
@@ -630,8 +656,8 @@ constexpr size_t lds_bytes() {
   return loop > kPoolTile ? loop : kPoolTile;
 }
 
-template <int DT, int TN, bool KPIPE, bool X3>
-int launch_one(const ConvParams& p, hipStream_t stream) {
+template <int DT, int TN, bool KPIPE, bool X3, bool WALK>
+int launch_one_w(const ConvParams& p, hipStream_t stream) {
   // the dynamic-LDS opt-in is a per-device function attribute: one flag per device, not per process
   constexpr int kMaxDevices = 64;
   static bool attr_set[kMaxDevices] = {};
@@ -641,15 +667,22 @@ int launch_one(const ConvParams& p, hipStream_t stream) {
   static_assert(lds <= 163840, "LDS budget");
   static_assert(!KPIPE || lds >= (size_t)kTileM * kPoolStride + 16, "pooling tile + zero slot must fit");
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
-    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN, KPIPE, X3>),
+    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN, KPIPE, X3, WALK>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
   }
   const int groups = (p.m_tiles + 7) / 8;
-  dim3 grid((unsigned)(groups * 8 * p.n_tiles)), block(kThreads);
-  hipLaunchKernelGGL((conv_igemm_kernel<DT, TN, KPIPE, X3>), grid, block, lds, stream, p);
+  const unsigned n_blocks = (unsigned)(groups * 8 * p.n_tiles);
+  dim3 grid(WALK ? std::min(n_blocks, kWalkGrid) : n_blocks), block(kThreads);
+  hipLaunchKernelGGL((conv_igemm_kernel<DT, TN, KPIPE, X3, WALK>), grid, block, lds, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+// p.walk picks the walking instantiation (a separate kernel: kernels.h, ConvParams::walk)
+template <int DT, int TN, bool KPIPE, bool X3>
+int launch_one(const ConvParams& p, hipStream_t stream) {
+  return p.walk ? launch_one_w<DT, TN, KPIPE, X3, true>(p, stream) : launch_one_w<DT, TN, KPIPE, X3, false>(p, stream);
 }
 
 template <int DT>

@@ -91,7 +91,7 @@ __device__ __forceinline__ int swz4(int r) { return (0x78 >> (2 * ((r >> 2) & 3)
 
 // K = kernel edge: k^3 taps, one weight slot / one barrier per (dz, dy) row of K taps
 template <int DT, int K, bool X3>
-__global__ __launch_bounds__(kThreads4) void conv4n_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv4n_tile(const ConvParams& p, const unsigned bid, const int tid_in) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
   constexpr int NB = X3 ? 2 : 1;             // weight fragment sets per column tile (pair modes: [W_hi ; W_hi] and [W_lo ; 0])
@@ -108,12 +108,12 @@ __global__ __launch_bounds__(kThreads4) void conv4n_kernel(const ConvParams p) {
   constexpr int APP = 8 / APR;               // ... and how many of them a wave issues per row
   static_assert(lds4<K>() <= 163840, "LDS budget");
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = tid_in, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cw = wave & 3, h = wave >> 2;    // Latin class and z half of this wave's two lines
 
   // XCD-aware block -> tile map: the column tiles of a group of 16 points stay on one XCD's L2
-  const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
+  const int xcd = bid & 7, grp = bid >> 3;
   const int n_tile = grp % p.n_tiles;
   const int m_tile = (grp / p.n_tiles) * 8 + xcd;
   if (m_tile >= p.m_tiles) return;
@@ -368,22 +368,53 @@ __global__ __launch_bounds__(kThreads4) void conv4n_kernel(const ConvParams p) {
   epi_pass(std::integral_constant<int, 1>{});
 }
 
-template <int DT, int K, bool X3>
-int launch_conv4n_one(const ConvParams& p, hipStream_t stream) {
+template <int DT, int K, bool X3, bool WALK>
+__global__ __launch_bounds__(kThreads4) void conv4n_kernel(const ConvParams p) {
+  if constexpr (!WALK) {
+    conv4n_tile<DT, K, X3>(p, blockIdx.x, threadIdx.x);
+  } else {
+    // walking launch (kernels.h: ConvParams::walk), a kernel of its own so that the one-tile-per-workgroup kernel keeps its register
+    // allocation: only the tiles below the live row count; the thread index is laundered per trip, otherwise hipcc hoists every
+    // per-lane address out of the tile loop and spills
+    unsigned n_blocks;
+    {
+      int npts = p.npoints;
+      if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
+      const unsigned m_live = (unsigned)((npts + kPts4 - 1) / kPts4);
+        n_blocks = (m_live + 7) / 8 * 8 * (unsigned)p.n_tiles;
+    }
+    for (unsigned bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+      if (bid != blockIdx.x) __syncthreads();    // the previous tile's epilogue is done with the LDS
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      conv4n_tile<DT, K, X3>(p, bid, tid);
+    }
+  }
+}
+
+template <int DT, int K, bool X3, bool WALK>
+int launch_conv4n_one_w(const ConvParams& p, hipStream_t stream) {
   constexpr int kMaxDevices = 64;
   static bool attr_set[kMaxDevices] = {};
   int dev = 0;
   NESTI_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
-    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4n_kernel<DT, K, X3>),
+    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4n_kernel<DT, K, X3, WALK>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds4<K>()));
     if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
   }
   const int groups = (p.m_tiles + 7) / 8;
-  dim3 grid((unsigned)(groups * 8 * p.n_tiles)), block(kThreads4);
-  hipLaunchKernelGGL((conv4n_kernel<DT, K, X3>), grid, block, lds4<K>(), stream, p);
+  const unsigned n_blocks = (unsigned)(groups * 8 * p.n_tiles);
+  dim3 grid(WALK ? std::min(n_blocks, kWalkGrid) : n_blocks), block(kThreads4);
+  hipLaunchKernelGGL((conv4n_kernel<DT, K, X3, WALK>), grid, block, lds4<K>(), stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+// p.walk picks the walking instantiation (a separate kernel: kernels.h, ConvParams::walk)
+template <int DT, int K, bool X3>
+int launch_conv4n_one(const ConvParams& p, hipStream_t stream) {
+  return p.walk ? launch_conv4n_one_w<DT, K, X3, true>(p, stream) : launch_conv4n_one_w<DT, K, X3, false>(p, stream);
 }
 
 template <int DT>

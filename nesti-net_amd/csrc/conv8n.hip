@@ -78,7 +78,7 @@ __device__ __forceinline__ uint4 lds128n(unsigned addr) {
 template <int K> constexpr int lds_bytes_n() { return kAOffN + 8 * (4 + (K - 1) / 2) * kTileN; }
 
 template <int DT, int K, bool X3>
-__global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned bid, const int tid_in) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
   constexpr int LO = (K - 1) / 2;
@@ -92,11 +92,11 @@ __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
   static_assert(NS * kSlot <= kAOffN, "weight slots must fit below the input chunk");
   static_assert((K & 1) == 1, "the weight-fragment ping-pong assumes an odd number of taps per row");
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = tid_in, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // XCD-aware block -> tile map: the 2 halves x n_tiles column pairs of a group of 4 points stay on one XCD's L2
-  const int xcd = blockIdx.x & 7, grp = blockIdx.x >> 3;
+  const int xcd = bid & 7, grp = bid >> 3;
   const int per_m = 2 * p.n_tiles;                       // p.n_tiles = 64-column pairs
   const int sub = grp % per_m;
   const int n_pair = sub >> 1, half = sub & 1;
@@ -374,8 +374,32 @@ __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
   epi_pass(std::integral_constant<int, 1>{});
 }
 
-template <int DT, int K, bool X3>
-int launch_conv8n_one(const ConvParams& p, hipStream_t stream) {
+template <int DT, int K, bool X3, bool WALK>
+__global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
+  if constexpr (!WALK) {
+    conv8n_tile<DT, K, X3>(p, blockIdx.x, threadIdx.x);
+  } else {
+    // walking launch (kernels.h: ConvParams::walk), a kernel of its own so that the one-tile-per-workgroup kernel keeps its register
+    // allocation: only the tiles below the live row count; the thread index is laundered per trip, otherwise hipcc hoists every
+    // per-lane address out of the tile loop and spills
+    unsigned n_blocks;
+    {
+      int npts = p.npoints;
+      if (p.npoints_ptr) npts = min(npts, *p.npoints_ptr);
+      const unsigned m_live = (unsigned)((npts + kPtsN - 1) / kPtsN);
+        n_blocks = (m_live + 7) / 8 * 8 * 2u * (unsigned)p.n_tiles;
+    }
+    for (unsigned bid = blockIdx.x; bid < n_blocks; bid += gridDim.x) {
+      if (bid != blockIdx.x) __syncthreads();    // the previous tile's epilogue is done with the LDS
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      conv8n_tile<DT, K, X3>(p, bid, tid);
+    }
+  }
+}
+
+template <int DT, int K, bool X3, bool WALK>
+int launch_conv8n_one_w(const ConvParams& p, hipStream_t stream) {
   constexpr int kMaxDevices = 64;
   static bool attr_set[kMaxDevices] = {};
   int dev = 0;
@@ -383,15 +407,22 @@ int launch_conv8n_one(const ConvParams& p, hipStream_t stream) {
   constexpr int lds = lds_bytes_n<K>();
   static_assert(lds <= 163840 && 1024 * kEpiStrideN <= lds, "LDS budget");
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
-    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8n_kernel<DT, K, X3>),
+    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8n_kernel<DT, K, X3, WALK>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
   }
   const int groups = (p.m_tiles + 7) / 8;
-  dim3 grid((unsigned)(groups * 8 * 2 * p.n_tiles)), block(kThreadsN);
-  hipLaunchKernelGGL((conv8n_kernel<DT, K, X3>), grid, block, lds, stream, p);
+  const unsigned n_blocks = (unsigned)(groups * 8 * 2 * p.n_tiles);
+  dim3 grid(WALK ? std::min(n_blocks, kWalkGrid) : n_blocks), block(kThreadsN);
+  hipLaunchKernelGGL((conv8n_kernel<DT, K, X3, WALK>), grid, block, lds, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+// p.walk picks the walking instantiation (a separate kernel: kernels.h, ConvParams::walk)
+template <int DT, int K, bool X3>
+int launch_conv8n_one(const ConvParams& p, hipStream_t stream) {
+  return p.walk ? launch_conv8n_one_w<DT, K, X3, true>(p, stream) : launch_conv8n_one_w<DT, K, X3, false>(p, stream);
 }
 
 template <int DT>

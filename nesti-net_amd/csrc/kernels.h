@@ -1,11 +1,15 @@
 // Kernel parameter blocks and launchers shared between the .hip files and the
 // host-side graph executor (model.hip).
 #pragma once
+#include <algorithm>
+
 #include "common.h"
 
 namespace nesti {
 
 constexpr int kTileM = 512;       // GEMM rows (voxels x points) per workgroup
+constexpr unsigned kWalkGrid = 1024;   // workgroups of a walking launch (ConvParams::walk): a multiple of 8, so a workgroup's tiles stay
+                                       // on its XCD (tile & 7 == blockIdx.x & 7); four per CU, enough to run a non-empty round
 constexpr int kRowBytes = 128;    // bytes of one K-chunk row in LDS (64 x 16-bit or 32 x f32)
 constexpr int kMaxTaps = 125;     // 5^3
 
@@ -54,6 +58,11 @@ struct ConvParams {
   // over the matrix pipes (conv.hip: tile_row).  0 = tile t holds rows [32t, 32t+32).  2 (2^3 volumes) = a tile is ONE voxel of
   // 32 points and the chunk sits in LDS in (voxel, point) order: padding skips whole tiles in all three axes.
   int remap;
+  // A launch that is probably EMPTY (a later round of a routing / flag list walk, a widening pass of the two-stage gate: the row
+  // count sits in device memory) is made with a small fixed grid whose workgroups WALK the tiles (tile = blockIdx.x, += gridDim.x,
+  // bounded by the live row count): an empty launch then costs a few hundred workgroups instead of one per tile of the capacity
+  // (a full-capacity grid of early-exiting workgroups costs ~1.1 ns each: 0.11 ms for 100k).  0 = one tile per workgroup.
+  int walk;
   // NESTI_BF16X3 / NESTI_F16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (two planes per
   // 64-channel group); out_coff / out_coff2 stay logical and every 16-bit store goes through split_col + two planes.
   int split;

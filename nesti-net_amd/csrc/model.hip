@@ -787,6 +787,8 @@ struct RunCtx {
   bool fast = false;             // NESTI_F16X3C filter pass: this tower runs in plain f16 on rc.m->packed_fast while the
                                  // MuPS tensor it reads keeps the model's pair layout (only the hi plane is read)
   int mix = 0;                   // expert towers in a pair mode: the layers whose packed_mix bit is set here run single-product
+  bool walk = false;             // this pass over a device-side list is probably empty (a later round, a widening pass): its conv
+                                 // launches use small walking grids (kernels.h: ConvParams::walk)
 };
 
 int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* ws, size_t ws_bytes, float** out) {
@@ -828,6 +830,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C * planes; p.mp_mode = op.mp_mode; p.mp_mode2 = op.mp_mode2; }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
+      p.walk = rc.walk ? 1 : 0;
       const int cat = conv_category(d, pl);
       const int tok = prof_begin(cat, rc.stream);
       // (a mixed layer is a plain f16 / bf16 kernel inside a pair-mode tower: kernel_dtype is the same element type either way)
@@ -932,6 +935,7 @@ int gate_cascade(const nesti_model* m, const void* X0, int B, unsigned char* ws,
     const int32_t* round_counts = fcounts + (pass == 0 ? kRoundCountsOff : kWidenRoundsOff);
     for (int r = 0; r < rounds; ++r) {
       RunCtx exact{m, cap, round_counts + r, flag_list + (size_t)r * cap, stream};
+      exact.walk = pass >= 1 || r >= 1;      // round 0 of pass 0 holds the flagged rows; everything after it is normally empty
       if (run_tower(exact, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
       if (launch_gate_recheck(logits, lstride, flag_list + (size_t)r * cap, round_counts + r, cap, E, keep, probs, expert,
                               m->cstat, stream))
@@ -971,6 +975,7 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
         const int32_t* list = lists + (size_t)e * B + (size_t)r * cap;
         const int32_t* cnt = ecounts + e * rounds + r;
         RunCtx rc{m, cap, cnt, list, stream, false, m->expert_mix};
+        rc.walk = r >= 1;                      // an expert sees ~1 / E of a batch: rounds after the first are normally empty
         if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
         if (launch_scatter3(out, ostride, list, cnt, cap, normals, stream)) return 1;
       } else {        // reference behaviour: every expert on every point -> [E,B,3], rows [r * cap, ...) of the batch per round
