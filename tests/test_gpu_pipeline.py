@@ -409,3 +409,25 @@ def test_reference_order_subsample_feeds_the_same_forward(gpu_device):
     assert not np.array_equal(again[0], got[0])
     with pytest.raises(ValueError):
         NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=4, subsample="sorted")
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f16x3"])
+def test_later_expert_rounds_run_through_the_walking_kernels(gpu_device, dtype):
+    """A batch larger than 8192 sizes the expert towers for a quarter of it and walks each routing list in four rounds; rounds
+    1 .. 3 are normally empty and are launched as small walking grids (csrc/kernels.h: ConvParams::walk).  With the RAW synthetic gate
+    nearly every query routes to ONE expert, so that expert's later rounds are FULL: the walking instantiations of conv_igemm /
+    conv8n / conv4n then do real work, and the result must equal the small-batch (single-round) result bit for bit."""
+    from nesti_net_amd import synth, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.pipeline import NormalEstimator
+    cfg = NestiConfig()
+    W = weights.synthetic_weights(cfg)                      # uncalibrated: the gate's output is almost input-independent
+    pts = synth.make_cloud("torus", n=30000, seed=5)[0]
+    q = np.arange(12000)
+    big = NormalEstimator(cfg, W, dtype=dtype, device=gpu_device, batch=12000).estimate(pts, pidx=q)
+    small = NormalEstimator(cfg, W, dtype=dtype, device=gpu_device, batch=3000).estimate(pts, pidx=q)
+    hist = np.bincount(big[1], minlength=cfg.n_experts)
+    assert hist.max() > 2 * 3072, hist.tolist()             # the favourite expert needs at least three of its four rounds
+    for a, b in zip(big, small):
+        assert np.array_equal(a, b)
+    assert np.all(np.isfinite(big[0]))
