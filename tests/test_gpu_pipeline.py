@@ -414,14 +414,17 @@ def test_reference_order_subsample_feeds_the_same_forward(gpu_device):
 @pytest.mark.parametrize("dtype", ["f16", "f16x3"])
 def test_later_expert_rounds_run_through_the_walking_kernels(gpu_device, dtype):
     """A batch larger than 8192 sizes the expert towers for a quarter of it and walks each routing list in four rounds; rounds
-    1 .. 3 are normally empty and are launched as small walking grids (csrc/kernels.h: ConvParams::walk).  With the RAW synthetic gate
-    nearly every query routes to ONE expert, so that expert's later rounds are FULL: the walking instantiations of conv_igemm /
+    1 .. 3 are normally empty and are launched as small walking grids (csrc/kernels.h: ConvParams::walk).  With a gate biased towards
+    one expert most queries route to it, so that expert's later rounds are FULL: the walking instantiations of conv_igemm /
     conv8n / conv4n then do real work, and the result must equal the small-batch (single-round) result bit for bit."""
     from nesti_net_amd import synth, weights
     from nesti_net_amd.config import NestiConfig
     from nesti_net_amd.pipeline import NormalEstimator
     cfg = NestiConfig()
-    W = weights.synthetic_weights(cfg)                      # uncalibrated: the gate's output is almost input-independent
+    W = dict(weights.synthetic_weights(cfg))
+    b4 = np.array(W["fc4noise/biases"], dtype=np.float32, copy=True)
+    b4[3] += 4.0                                            # a gate that strongly prefers expert 3 (fc4 has no batch norm)
+    W["fc4noise/biases"] = b4
     pts = synth.make_cloud("torus", n=30000, seed=5)[0]
     q = np.arange(12000)
     big = NormalEstimator(cfg, W, dtype=dtype, device=gpu_device, batch=12000).estimate(pts, pidx=q)
