@@ -423,7 +423,7 @@ def test_later_expert_rounds_run_through_the_walking_kernels(gpu_device, dtype):
     cfg = NestiConfig()
     W = dict(weights.synthetic_weights(cfg))
     b4 = np.array(W["fc4noise/biases"], dtype=np.float32, copy=True)
-    b4[3] += 4.0                                            # a gate that strongly prefers expert 3 (fc4 has no batch norm)
+    b4[3] += 1000.0                                         # a gate that strongly prefers expert 3 (fc4 has no batch norm)
     W["fc4noise/biases"] = b4
     pts = synth.make_cloud("torus", n=30000, seed=5)[0]
     q = np.arange(12000)
