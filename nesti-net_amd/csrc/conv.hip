@@ -326,6 +326,9 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
     }
   }
 
+#ifdef IGEMM_EMPTY        // timing-only experiment: workgroup dispatch + the first chunk's staging, nothing else
+  if (KPIPE) return;
+#endif
   // ---- epilogue (the barrier that ended the last step guarantees nobody still reads A/B) -------
 #ifdef IGEMM_NO_EPILOGUE  // timing-only experiment (wrong results): the main loop alone (the accumulators stay live through a
   if (KPIPE) {            // store that never happens)
@@ -342,6 +345,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
 #endif
   const int out_esz = p.out_f32 ? 4 : kEsz;
   unsigned char* out_b = reinterpret_cast<unsigned char*>(p.out);
+#ifdef IGEMM_NO_STORE     // timing-only experiment: the epilogue's LDS / VALU work without its global stores (a row bound the compiler
+  const long long total_rows_all = total_rows;   // cannot see through: every `gr < total_rows` below fails at run time)
+#define total_rows (p.npoints < 0 ? total_rows_all : 0ll)
+#endif
   const bool second = n_tile >= p.split_tile;            // conv4 half of a merged conv1|conv4 launch
   const int n_local = second ? n_tile - p.split_tile : n_tile;
   const int out_col0 = (second ? p.out_coff2 : p.out_coff) + n_local * TN;
@@ -622,6 +629,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
     }
   }
 }
+
+#ifdef IGEMM_NO_STORE
+#undef total_rows
+#endif
 
 template <int DT, int TN, bool KPIPE, bool X3, bool WALK>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p) {
