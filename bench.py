@@ -332,6 +332,14 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
             if pj.get("dtype") == dtype and pj.get("batch") == run["batch"] and pj.get("calibrated_gate") == calibrated:
                 traffic = pj["kernels"]["conv"]["hbm_bytes_per_query"] * rank0_pts / max(1, conv_n)
                 src = "profiles/%s (separate --pmc passes of this bench configuration)" % name
+                # the same counters per kernel class (plain + pair launches of the class), against THIS run's class times: the HBM-side
+                # rate each class sustains (rocprof bytes / hipEvent time; 8 TB/s peak) -- none of them is HBM-bound
+                for cname, ent in by_kernel.items():
+                    b = sum(pj["kernels"].get("conv:" + cname + sfx, {}).get("hbm_bytes_per_query", 0.0) for sfx in ("", "_pair"))
+                    if b and ent["ms_per_step"]:
+                        ent["hbm_MB_per_query_measured"] = b / 1e6
+                        ent["hbm_GBps_measured"] = b * (rank0_pts / steps) / (ent["ms_per_step"] / 1e3) / 1e9
+                        ent["hbm_frac_of_8TBps"] = ent["hbm_GBps_measured"] / 8000.0
     return {
         "bound": "mfma", "kernel": "conv8n_kernel + conv4n_kernel + conv_igemm_kernel (all conv3d / fc layers)", "achieved": tot[1], "peak": peak,
         "unit": "TFLOP/s", "frac": tot[1] / peak, "traffic": traffic, "traffic_source": src,
