@@ -71,7 +71,8 @@ def fit_batch(cfg, dtype, batch, device, lanes=2, reserve=2 << 30):
                   for t in range(-1, max(1, cfg.n_towers))]
         if dtype == "f16x3c":                  # the recheck rounds run the f16x3 gate on a quarter of a large batch
             towers.append(lib.nesti_tower_workspace_bytes(ctypes.byref(c), DTYPES["f16x3"], -1, ccap))
-        arena = max(towers) + batch * (x0_per_q + 160)
+        staging = 0 if cfg.n_gaussians == 8 else cfg.n_scales * cfg.num_point * 12     # 3^3 grid: the patch tensor is materialised
+        arena = max(towers) + batch * (x0_per_q + staging + 160)
         if lanes * arena <= free:
             break
         batch = max(256, (batch // 2 + 255) // 256 * 256)
