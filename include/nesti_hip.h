@@ -205,7 +205,9 @@ int nesti_model_gate_error_import(nesti_model_t* m, const float* src_dev, int n,
 int nesti_experiment_mix_enable(int on); /* process-wide, BEFORE nesti_model_create: pack the extra single-product copies (default off) */
 int nesti_model_set_expert_mix(nesti_model_t* m, int mask);
 /* The same switch for the gating net of a NESTI_F16X3 / NESTI_BF16X3 model (non-cascade nesti_gate_forward / nesti_forward):
- * on != 0 runs ALL its k^3 tap layers at 8^3 / 4^3 single-product, the 1x1x1 / FC layers stay three-product ("medium" gate). */
+ * on != 0 runs ALL its k^3 tap layers at 8^3 / 4^3 single-product, the 1x1x1 / FC layers stay three-product ("medium" gate);
+ * on == 2 additionally rounds every layer's output to 16 bits (lo plane = 0): the numerics of a plain-f16 gate whose 1x1x1 / FC
+ * layers multiply by the exact weights (hi * W_hi + hi * W_lo) -- the "exact-weight filter" of profiles/r05_gate_medium.txt. */
 int nesti_model_set_gate_mix(nesti_model_t* m, int on);
 
 /* Workspace of ONE tower for `batch` queries, from the configuration alone (no device needed): tower = -1 the gating

@@ -787,6 +787,7 @@ struct RunCtx {
   bool fast = false;             // NESTI_F16X3C filter pass: this tower runs in plain f16 on rc.m->packed_fast while the
                                  // MuPS tensor it reads keeps the model's pair layout (only the hi plane is read)
   int mix = 0;                   // expert towers in a pair mode: the layers whose packed_mix bit is set here run single-product
+  bool zero_lo = false;          // experiment (gate_mix == 2): every layer writes its outputs rounded to 16 bits (lo plane = 0)
   bool walk = false;             // this pass over a device-side list is probably empty (a later round, a widening pass): its conv
                                  // launches use small walking grids (kernels.h: ConvParams::walk)
 };
@@ -815,7 +816,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       // pair modes: strides and the input offset are physical (a 64-aligned logical offset x 3), output column
       // offsets stay logical (kernels.h: ConvParams::split); an fp32 output buffer is an ordinary one
       const int planes = act_planes(dtype);
-      p.split = planes > 1 ? 1 : 0;
+      p.split = planes > 1 ? (rc.zero_lo ? 2 : 1) : 0;
       const int in_planes = ext_in ? x0_planes : planes;
       p.in_cstride = (op.in_cstride ? op.in_cstride : T.bufs[op.in_buf].C) * in_planes; p.in_coff = op.in_coff * in_planes;
       // distance between consecutive K chunks of a PLAIN kernel's input row: 128 B, except in the NESTI_F16X3C filter pass,
@@ -949,6 +950,7 @@ int gate_cascade(const nesti_model* m, const void* X0, int B, unsigned char* ws,
 int gate_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_ws, size_t tower_bytes_,
               float* probs, int32_t* expert, int32_t* counts, int32_t* lists, hipStream_t stream) {
   RunCtx rc{m, B, nullptr, nullptr, stream, false, m->gate_mix ? (1 << kGateMixBit) : 0};
+  rc.zero_lo = m->gate_mix == 2;
   float* logits = nullptr;
   prof_phase(NESTI_PHASE_GATE);
   if (run_tower(rc, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
@@ -1151,7 +1153,8 @@ int nesti_model_set_expert_mix(nesti_model_t* m, int mask) {
 int nesti_model_set_gate_mix(nesti_model_t* m, int on) {
   if (!m) NESTI_FAIL("nesti_model_set_gate_mix: null model");
   if (on && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_gate_mix: pair-mode experts_n_est models (8^3 grid) created after nesti_experiment_mix_enable(1) only");
-  m->gate_mix = on ? 1 : 0;
+  m->gate_mix = on == 2 ? 2 : on ? 1 : 0;   // 2: additionally every layer's OUTPUT is rounded to 16 bits (lo = 0): the numerics of a
+                                            // plain-f16 gate whose 1x1x1 / FC layers multiply by the exact weights (hi * W_hi + hi * W_lo)
   return 0;
 }
 

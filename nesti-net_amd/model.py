@@ -134,7 +134,7 @@ class NestiNet:
 
     def set_gate_mix(self, on):
         """EXPERIMENT: the (non-cascade) pair-mode gating net with single-product tap layers (``nesti_model_set_gate_mix``)."""
-        _lib.check(self.lib.nesti_model_set_gate_mix(self._handle, int(bool(on))), "nesti_model_set_gate_mix")
+        _lib.check(self.lib.nesti_model_set_gate_mix(self._handle, int(on)), "nesti_model_set_gate_mix")
 
     def export_gate_error(self, dst, stream=None):
         """Write this model's ``max_margin_err`` into the one-element f32 device tensor ``dst`` (no synchronisation)."""

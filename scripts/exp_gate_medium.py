@@ -34,8 +34,8 @@ W = calibrate_gate(cfg, weights.synthetic_weights(cfg), sp, sn, device=dev)
 del sp, sn
 net3 = NestiNet(cfg, W, dtype="f16x3", device=dev, max_batch=B)
 net1 = NestiNet(cfg, W, dtype="f16", device=dev, max_batch=B)
-out = {"full": [], "medium": [], "f16": []}
-ms = {"full": 0.0, "medium": 0.0, "f16": 0.0}
+out = {"full": [], "medium": [], "xw": [], "f16": []}
+ms = {"full": 0.0, "medium": 0.0, "xw": 0.0, "f16": 0.0}
 
 
 def timed(fn):
@@ -52,7 +52,9 @@ for done in range(0, N, B):
     take = min(B, N - done)
     p, n = cp.build(done, take)
     m3, m1 = net3.mups(p, n), net1.mups(p, n)
-    for key, net, mups, mix in (("full", net3, m3, 0), ("medium", net3, m3, 1), ("f16", net1, m1, 0)):
+    # "xw": every activation rounded to f16, tap layers single-product, 1x1x1 / FC layers hi * (W_hi + W_lo): the NUMERICS of a plain-f16
+    # filter whose 1x1x1 / FC layers use the exact weights (its time here is the emulation's, not that filter's)
+    for key, net, mups, mix in (("full", net3, m3, 0), ("medium", net3, m3, 1), ("xw", net3, m3, 2), ("f16", net1, m1, 0)):
         if net is net3:
             net3.set_gate_mix(mix)
         (probs, _), t = timed(lambda: net.gate(mups))
@@ -68,7 +70,7 @@ lines = ["three-stage gate experiment (scripts/exp_gate_medium.py): %d queries, 
          "gate pass per %d queries: full f16x3 %.1f ms, medium (taps single-product, 1x1 / FC three-product) %.1f ms, plain f16 %.1f ms"
          % (N, ms["full"], ms["medium"], ms["f16"])]
 res = {"queries": N, "ms": ms}
-for key in ("f16", "medium"):
+for key in ("f16", "xw", "medium"):
     l = L[key]
     a = np.argmax(l, axis=1)
     rows = np.arange(N)
@@ -96,6 +98,10 @@ f1, f2 = float(flag1.mean()), float(flag2.mean())
 now = f1 * ms["full"]
 three = f1 * ms["medium"] + f2 * ms["full"]
 res["projection"] = {"stage1_flagged": f1, "stage2_flagged": f2, "recheck_ms_now": now, "recheck_ms_three_stage": three}
+lines.append("exact-weight filter (xw): sigma %.4g vs the plain filter's %.4g; 1.5 x max -> %.2f %% of the queries rechecked instead of %.2f %%: "
+             "recheck %.1f -> %.1f ms per %d queries if the filter's 1x1x1 / FC layers used the exact weights"
+             % (res["xw"]["sigma"], res["f16"]["sigma"], 100 * res["xw"]["frac_below_threshold"], 100 * res["f16"]["frac_below_threshold"],
+                res["f16"]["frac_below_threshold"] * ms["full"], res["xw"]["frac_below_threshold"] * ms["full"], N))
 lines.append("filter flags %.2f %%; of those the medium gate leaves %.2f %% of all queries for the full gate" % (100 * f1, 100 * f2))
 lines.append("recheck cost per %d queries: today %.1f ms (flagged x full)  ->  three-stage %.1f ms (flagged x medium + still-flagged x full): %+.1f ms"
              % (N, now, three, three - now))
