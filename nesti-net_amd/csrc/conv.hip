@@ -85,18 +85,25 @@ struct SwzKey {
 // and one set of fragment reads feeds three MFMAs (lo * W_hi, hi * W_hi, hi * W_lo): 1.5x the MFMAs per LDS byte, per
 // staged byte and per barrier of the plain kernel.
 // one (M tile, N tile) of the layer; `bid` is the position in the XCD-aware block order (blockIdx.x of a one-tile-per-workgroup launch)
-template <int DT, int TN, bool KPIPE, bool X3>
+// X2 (kernels.h: ConvParams::x2; KPIPE, 16-bit, not X3): plain activations x pair-packed weights.  A K chunk is 32 channels: the A
+// rows are 64 B (16-B slot XOR-swizzled by (row >> 2) & 3, which makes the ds_read_b128 lane groups conflict-free on 64-byte rows),
+// the B rows are the pair packing's [W_hi k0..31 | W_lo k0..31]; per 16-channel K-step one A fragment set feeds hi * W_hi and hi * W_lo.
+template <int DT, int TN, bool KPIPE, bool X3, bool X2 = false>
 __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsigned bid, const int tid_in) {
+  static_assert(!X2 || (KPIPE && !X3 && DT != NESTI_F32), "X2 is a 16-bit one-tap variant");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NI = TN / 32;
   constexpr int kBTile = TN * kRowBytes;
   constexpr int kBVec = TN / 64;                  // 1-KiB pieces of a weight tile per wave
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
   constexpr int kNA = KPIPE ? 2 : 1;              // A buffers
+  constexpr int kARow = X2 ? 64 : kRowBytes;      // bytes of one A row in LDS
+  constexpr int kABuf = kTileM * kARow;           // one A buffer
+  constexpr int kAPieces = kABuf / (8 * 1024);    // 1-KiB staging pieces per wave and chunk
   unsigned char* As = smem;
-  unsigned char* Bs = smem + kNA * kABytes;
+  unsigned char* Bs = smem + kNA * kABuf;
   constexpr int kNB = KPIPE ? 2 : 4;              // weight-tile slots (general variant: 2 groups of 2 taps)
-  constexpr int kZeroOff = kNA * kABytes + kNB * kBTile;   // all-zero 128-B row (general variant only)
+  constexpr int kZeroOff = kNA * kABuf + kNB * kBTile;   // all-zero 128-B row (general variant only)
 
   const int tid = tid_in, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,11 +126,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
   if (r0 >= total_rows) return;
 
   // ---- A staging: wave w, piece j covers LDS rows (w*8+j)*8 .. +8; lane -> (row, slot') ----------
-  long long a_off[8];
+  long long a_off[kAPieces];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int row_l = (wave * 8 + j) * 8 + (lane >> 3);
-    const int slot = (lane & 7) ^ swz_key(row_l);   // inverse swizzle on the SOURCE
+  for (int j = 0; j < kAPieces; ++j) {
+    // X2: 64-byte rows -- a piece is 16 rows x 4 slots
+    const int row_l = X2 ? (wave * kAPieces + j) * 16 + (lane >> 2) : (wave * 8 + j) * 8 + (lane >> 3);
+    const int slot = X2 ? (lane & 3) ^ ((row_l >> 2) & 3) : (lane & 7) ^ swz_key(row_l);   // inverse swizzle on the SOURCE
     // remap == 2: LDS row (block b, point pt) <- global row 8 pt + vox2(b)
     const long long gr = r0 + (remap == 2 ? ((row_l & 63) << 3) + vox2(row_l >> 6) : row_l);
     if (gr < total_rows) {
@@ -143,17 +151,19 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic segment
   auto stage_a = [&](int c, int a_buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
+    for (int j = 0; j < kAPieces; ++j)
       if (a_off[j] >= 0)
-        glds16(in_b + a_off[j] + (X3 ? (long long)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (c & 1) * 64 : (long long)c * p.in_chunk_bytes),
-               lds0 + a_buf * kABytes + (wave * 8 + j) * 1024);
+        glds16(in_b + a_off[j] + (X3   ? (long long)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (c & 1) * 64
+                                  : X2 ? (long long)(c >> 1) * p.in_chunk_bytes + (c & 1) * 64      // 32-channel chunk c of a plain / hi-plane row
+                                       : (long long)c * p.in_chunk_bytes),
+               lds0 + a_buf * kABuf + (wave * kAPieces + j) * 1024);
   };
   auto stage_b = [&](int c, int t, int b_buf) __attribute__((always_inline)) {
     const unsigned char* src = w_tile + ((size_t)c * p.n_taps + t) * kBTile;
 #pragma unroll
     for (int q = 0; q < kBVec; ++q) {
       const int piece = wave * kBVec + q;
-      glds16(src + piece * 1024 + lane * 16, lds0 + kNA * kABytes + b_buf * kBTile + piece * 1024);
+      glds16(src + piece * 1024 + lane * 16, lds0 + kNA * kABuf + b_buf * kBTile + piece * 1024);
     }
   };
 
@@ -233,6 +243,41 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
       }
       return;
     }
+    if constexpr (X2) {
+      // per 16-channel K-step t: one A fragment set (the lane's 16 B of the 64-byte row), W_hi and W_lo of the NI column tiles
+      uint4 a0[2], a1[2], bh[NI], bl[NI];
+      auto ld_a = [&](int t, uint4 (&f)[2]) __attribute__((always_inline)) {
+        const int slot = t * 2 + khalf;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) f[mi] = *reinterpret_cast<const uint4*>(Acur + a_addr[mi] + ((slot ^ a_sw[mi]) << 4));
+      };
+      auto ld_b = [&](int t, int lo, uint4 (&f)[NI]) __attribute__((always_inline)) {
+        const int slot = lo * 4 + t * 2 + khalf;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          f[ni] = *reinterpret_cast<const uint4*>(Bcur + ni * 32 * kRowBytes + b_row + ((slot ^ b_sw) << 4));
+      };
+      auto mm = [&](const uint4 (&af)[2], const uint4 (&bf)[NI]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) mma<DT>(acc[mi][ni], af[mi], bf[ni]);
+      };
+      ld_a(0, a0);
+      ld_b(0, 0, bh);
+      ld_b(0, 1, bl);
+      ld_a(1, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(a0, bh);
+      ld_b(1, 0, bh);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(a0, bl);
+      ld_b(1, 1, bl);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(a1, bh);
+      mm(a1, bl);
+      return;
+    }
     uint4 a[2][2], b[2][NI];
     auto load_frags = [&](int kk, uint4 (&af)[2], uint4 (&bf)[NI]) __attribute__((always_inline)) {
       const int slot = kk * 2 + khalf;
@@ -263,7 +308,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
     // ---- one tap: software pipeline over input-channel chunks --------------------------------
     int a_addr[2], a_sw[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) { a_addr[mi] = rrow[mi] * kRowBytes; a_sw[mi] = swz_key(rrow[mi]); }
+    for (int mi = 0; mi < 2; ++mi) { a_addr[mi] = rrow[mi] * kARow; a_sw[mi] = X2 ? (rrow[mi] >> 2) & 3 : swz_key(rrow[mi]); }
     stage_a(0, 0);
     stage_b(0, 0, 0);
     wait_vm0();
@@ -278,7 +323,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
         stage_a(c + 1, cur ^ 1);
         stage_b(c + 1, 0, cur ^ 1);
       }
-      compute(true, true, As + cur * kABytes, Bs + cur * kBTile, a_addr, a_sw);
+      compute(true, true, As + cur * kABuf, Bs + cur * kBTile, a_addr, a_sw);
       wait_vm0();
       __syncthreads();
     }
@@ -634,10 +679,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
 #undef total_rows
 #endif
 
-template <int DT, int TN, bool KPIPE, bool X3, bool WALK>
+template <int DT, int TN, bool KPIPE, bool X3, bool WALK, bool X2 = false>
 __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p) {
   if constexpr (!WALK) {
-    conv_igemm_tile<DT, TN, KPIPE, X3>(p, blockIdx.x, threadIdx.x);
+    conv_igemm_tile<DT, TN, KPIPE, X3, X2>(p, blockIdx.x, threadIdx.x);
   } else {
     // walking launch (kernels.h: ConvParams::walk), a kernel of its own so that the one-tile-per-workgroup kernel keeps its register
     // allocation: only the tiles below the live row count; the thread index is laundered per trip, otherwise hipcc hoists every
@@ -654,7 +699,7 @@ __global__ __launch_bounds__(kThreads) void conv_igemm_kernel(const ConvParams p
       if (bid != blockIdx.x) __syncthreads();    // the previous tile's epilogue is done with the LDS
       int tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
-      conv_igemm_tile<DT, TN, KPIPE, X3>(p, bid, tid);
+      conv_igemm_tile<DT, TN, KPIPE, X3, X2>(p, bid, tid);
     }
   }
 }
@@ -667,7 +712,7 @@ constexpr size_t lds_bytes() {
   return loop > kPoolTile ? loop : kPoolTile;
 }
 
-template <int DT, int TN, bool KPIPE, bool X3, bool WALK>
+template <int DT, int TN, bool KPIPE, bool X3, bool WALK, bool X2 = false>
 int launch_one_w(const ConvParams& p, hipStream_t stream) {
   // the dynamic-LDS opt-in is a per-device function attribute: one flag per device, not per process
   constexpr int kMaxDevices = 64;
@@ -678,14 +723,14 @@ int launch_one_w(const ConvParams& p, hipStream_t stream) {
   static_assert(lds <= 163840, "LDS budget");
   static_assert(!KPIPE || lds >= (size_t)kTileM * kPoolStride + 16, "pooling tile + zero slot must fit");
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
-    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN, KPIPE, X3, WALK>),
+    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<DT, TN, KPIPE, X3, WALK, X2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
   }
   const int groups = (p.m_tiles + 7) / 8;
   const unsigned n_blocks = (unsigned)(groups * 8 * p.n_tiles);
   dim3 grid(WALK ? std::min(n_blocks, kWalkGrid) : n_blocks), block(kThreads);
-  hipLaunchKernelGGL((conv_igemm_kernel<DT, TN, KPIPE, X3, WALK>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<DT, TN, KPIPE, X3, WALK, X2>), grid, block, lds, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -700,13 +745,19 @@ template <int DT>
 int launch_dt(const ConvParams& p, int TN, hipStream_t stream) {
   const bool kpipe = (p.n_taps == 1);
   if constexpr (DT != NESTI_F32) {
+    if (p.x2) {          // plain activations x pair-packed weights (kernels.h: ConvParams::x2): one-tap layers only; never a walking launch
+      if (!kpipe || p.x3native || p.walk) NESTI_FAIL("launch_conv: x2 is the filter pass's 1x1x1 / FC variant");
+      if (TN == 128) return launch_one_w<DT, 128, true, false, false, true>(p, stream);
+      if (TN == 64) return launch_one_w<DT, 64, true, false, false, true>(p, stream);
+      NESTI_FAIL("launch_conv: unsupported N tile");
+    }
     if (p.x3native) {
       if (TN == 128) return kpipe ? launch_one<DT, 128, true, true>(p, stream) : launch_one<DT, 128, false, true>(p, stream);
       if (TN == 64) return kpipe ? launch_one<DT, 64, true, true>(p, stream) : launch_one<DT, 64, false, true>(p, stream);
       NESTI_FAIL("launch_conv: unsupported N tile");
     }
   }
-  if (p.x3native) NESTI_FAIL("launch_conv: the pair K loop is for the 16-bit kernels");
+  if (p.x3native || p.x2) NESTI_FAIL("launch_conv: the pair / exact-weight K loops are for the 16-bit kernels");
   if (TN == 128) return kpipe ? launch_one<DT, 128, true, false>(p, stream) : launch_one<DT, 128, false, false>(p, stream);
   if (TN == 64) return kpipe ? launch_one<DT, 64, true, false>(p, stream) : launch_one<DT, 64, false, false>(p, stream);
   NESTI_FAIL("launch_conv: unsupported N tile");

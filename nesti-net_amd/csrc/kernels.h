@@ -66,6 +66,10 @@ struct ConvParams {
   // NESTI_BF16X3 / NESTI_F16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (two planes per
   // 64-channel group); out_coff / out_coff2 stay logical and every 16-bit store goes through split_col + two planes.
   int split;
+  int x2;              // 1x1x1 / FC layers of the NESTI_F16X3C filter pass (conv_igemm_kernel, KPIPE): PLAIN 16-bit activations times the
+                       // pair-packed weights [W_hi | W_lo] -- hi * W_hi + hi * W_lo, i.e. the layer multiplies by its exact weights.  K chunks
+                       // of 32 channels: 64-byte A rows, 128-byte B rows; n_chunks / acc_scale / wpk are the pair packing's.  These layers
+                       // are fill-bound, so the second product is nearly free, and it removes the weight-rounding half of the filter's error
   int x3native;        // pair modes: the kernels' pair K loop (conv.hip / conv8n.hip: X3) -- K chunks [hi | lo] x [W_hi | W_lo], three MFMAs
                        // per fragment set; the packed weights follow (model.hip: PackedLayer::x3n)
   float acc_scale;     // the accumulators are multiplied by this before the bias (1, or 2^-s when the layer's packed weights

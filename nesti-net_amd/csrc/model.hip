@@ -806,10 +806,17 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       const LayerDesc& d = rc.m->graph.layers[op.layer];
       const bool mixl = !rc.fast && rc.mix && op.layer < (int)rc.m->packed_mix.size() && rc.m->packed_mix[op.layer].wpk &&
                         ((rc.mix >> rc.m->packed_mix[op.layer].mix_bit) & 1);
-      const PackedLayer& pl = rc.fast ? rc.m->packed_fast[op.layer] : mixl ? rc.m->packed_mix[op.layer] : rc.m->packed[op.layer];
+      // NESTI_F16X3C filter pass: its one-tap layers (1x1x1 conv1|conv4, FC) multiply the plain-f16 activations by the model's own
+      // PAIR-packed weights (conv_igemm_kernel's X2 loop: hi * W_hi + hi * W_lo).  Those layers are fill-bound, so the second product
+      // costs ~20 % more weight-tile fill and no matrix-pipe time that shows, and it removes the weight-rounding part of their error:
+      // the filter's sigma on a logit difference drops from 0.021 to 0.012 (profiles/r05_gate_medium.txt), the threshold with it
+      const bool x2l = rc.fast && rc.m->packed_fast[op.layer].wpk == nullptr;
+      const PackedLayer& pl = x2l ? rc.m->packed[op.layer] : rc.fast ? rc.m->packed_fast[op.layer]
+                              : mixl ? rc.m->packed_mix[op.layer] : rc.m->packed[op.layer];
       ConvParams p;
       memset(&p, 0, sizeof(p));
       p.in_pair = mixl ? 1 : 0;
+      p.x2 = x2l ? 1 : 0;
       p.in = ptr[op.in_buf]; p.out = ptr[op.out_buf]; p.wpk = pl.wpk; p.bias = pl.bias;
       p.npoints_ptr = rc.npoints_ptr; p.point_index = ext_in ? rc.point_index : nullptr;
       p.npoints = rc.NB;
@@ -824,7 +831,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.in_chunk_bytes = kRowBytes * (planes == 1 ? in_planes : 1);
       p.out_cstride = T.bufs[op.out_buf].C * (op.out_f32 ? 1 : planes); p.out_coff = op.out_coff;
       p.n_chunks = pl.n_chunks; p.n_taps = pl.n_taps; p.tap_k = d.k; p.log2S = d.log2S; p.s_real = d.s_real;
-      p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0; p.acc_scale = pl.acc_scale; p.x3native = pl.x3n ? 1 : 0;
+      p.relu = d.relu ? 1 : 0; p.out_f32 = op.out_f32 ? 1 : 0; p.acc_scale = pl.acc_scale; p.x3native = (pl.x3n && !x2l) ? 1 : 0;
       const long long rows = (long long)rc.NB << (3 * d.log2S);
       p.m_tiles = pl.kind == 3 ? (rc.NB + 15) / 16 : pl.kind == 2 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
@@ -1118,8 +1125,13 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
   }
   if (m->cascade) {
     m->packed_fast.resize(m->graph.layers.size());
-    for (const Op& op : m->graph.gate.ops)
-      if (op.kind == Op::CONV && pack_layer(m->graph.layers[op.layer], tt, NESTI_F16, &m->packed_fast[op.layer])) return 1;
+    for (const Op& op : m->graph.gate.ops) {
+      if (op.kind != Op::CONV) continue;
+      // the tap layers in plain f16; the one-tap layers (conv_igemm_kernel, kind 0, a single tap) keep an EMPTY entry: the filter pass
+      // runs them on the model's pair-packed weights (run_tower: x2l)
+      if (m->packed[op.layer].kind == 0 && m->packed[op.layer].n_taps == 1) continue;
+      if (pack_layer(m->graph.layers[op.layer], tt, NESTI_F16, &m->packed_fast[op.layer])) return 1;
+    }
     NESTI_CHECK_HIP(hipMalloc((void**)&m->cstat, 64));
     NESTI_CHECK_HIP(hipMemset(m->cstat, 0, 64));
   }

@@ -33,15 +33,20 @@ def case(gpu_device):
     n_all = x3.experts(x3.mups(points, n_eff), None).clone()          # [E, B, 3]: every expert's f16x3 normal of every query
     f16 = NestiNet(cfg, W, dtype="f16", device=gpu_device, max_batch=B)
     p16, e16 = [t.clone() for t in f16.gate(f16.mups(points, n_eff))]
+    # the FILTER pass's own decisions (tau = 0: nothing is rechecked): plain-f16 activations and tap layers, 1x1x1 / FC layers on
+    # the exact pair-packed weights -- close to, but since round 5 not identical with, the plain f16 model's gate above
+    fl = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
+    fl.set_gate_margin(0.0)
+    pfl, efl = [t.clone() for t in fl.gate(fl.mups(points, n_eff))]
     torch.cuda.synchronize()
-    del x3, f16
+    del x3, f16, fl
     torch.cuda.empty_cache()
-    return cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16
+    return cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16, pfl, efl
 
 
 def test_tau_infinite_equals_f16x3_bitwise_and_counts_every_query(case, gpu_device):
     from nesti_net_amd.model import NestiNet
-    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16, pfl, efl = case
     net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
     net.set_gate_margin(1e30)
     out = net(points, n_eff)
@@ -49,7 +54,7 @@ def test_tau_infinite_equals_f16x3_bitwise_and_counts_every_query(case, gpu_devi
     for a, b in zip(out, ref):
         assert torch.equal(a, b)
     assert st["queries"] == B and st["rechecked"] == B
-    assert st["changed"] == int((e16 != ref[1]).sum().item())          # what the f16 gate alone would have got wrong
+    assert st["changed"] == int((efl != ref[1]).sum().item())          # what the filter pass alone would have got wrong
     assert 0 < st["max_margin_err"] < 1.0
     # .gate() / .experts() (the reference-shaped pieces) go through the same two stages
     mups = net.mups(points, n_eff)
@@ -61,13 +66,24 @@ def test_tau_infinite_equals_f16x3_bitwise_and_counts_every_query(case, gpu_devi
 
 def test_tau_zero_keeps_the_f16_gate_and_routes_f16x3_experts(case, gpu_device):
     from nesti_net_amd.model import NestiNet
-    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16, pfl, efl = case
     net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
     net.set_gate_margin(0.0)
     normals, expert, probs = net(points, n_eff)
     st = net.cascade_stats()
     assert st["rechecked"] == 0 and st["changed"] == 0 and st["max_margin_err"] == 0.0
-    assert torch.equal(expert, e16) and torch.equal(probs, p16)        # the filter pass IS the plain f16 gate (hi plane of the pair MuPS)
+    # the filter pass alone decided: plain-f16 activations (hi plane of the pair MuPS), tap layers in plain f16, and -- since round
+    # 5 -- the 1x1x1 / FC layers multiplied by their EXACT (pair-packed) weights.  It is therefore no longer the plain f16 model's
+    # gate bit for bit, but closer to the f16x3 gate than that one: fewer arg-max differences, smaller probability error.
+    flips_filter = int((expert != ref[1]).sum().item())
+    flips_f16 = int((e16 != ref[1]).sum().item())
+    perr_filter = float((probs - ref[2]).abs().max().item())
+    perr_f16 = float((p16 - ref[2]).abs().max().item())
+    print("filter alone: %d arg-max differences vs f16x3 (plain f16 gate: %d), prob err %.4g (plain f16: %.4g)"
+          % (flips_filter, flips_f16, perr_filter, perr_f16))
+    assert flips_filter <= flips_f16 and perr_filter <= perr_f16 and perr_filter < 0.03
+    assert not torch.equal(probs, p16)
+    assert torch.equal(expert, efl) and torch.equal(probs, pfl)         # forward() and gate() run the same filter
     pick = n_all[expert.long(), torch.arange(B, device=gpu_device)]
     assert torch.equal(normals, pick)                                   # f16x3 normals of whatever expert was chosen
 
@@ -75,7 +91,7 @@ def test_tau_zero_keeps_the_f16_gate_and_routes_f16x3_experts(case, gpu_device):
 def test_calibrated_margin_reproduces_the_f16x3_decisions(case, gpu_device):
     from nesti_net_amd.calibrate import calibrate_gate_margin
     from nesti_net_amd.model import NestiNet
-    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16, pfl, efl = case
     net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
     assert calibrate_gate_margin(net, points[:100], n_eff[:100]) == float("inf")   # too few queries to calibrate on: no filtering
     assert net.cascade_stats()["tau"] > 1e29
@@ -93,10 +109,10 @@ def test_calibrated_margin_reproduces_the_f16x3_decisions(case, gpu_device):
     if st["max_margin_err"] <= tau / 1.5:
         assert st["widened"] == 0 and st["tau_eff"] == pytest.approx(tau)
     assert torch.equal(expert, ref[1]) and torch.equal(normals, ref[0])
-    # probabilities: f16x3's on the rechecked rows, the f16 gate's elsewhere
+    # probabilities: f16x3's on the rechecked rows, the filter pass's elsewhere (within its error of f16x3's)
     same = (probs == ref[2]).all(dim=1)
     assert int(same.sum().item()) >= st["rechecked"]
-    assert torch.equal(probs[~same], p16[~same])
+    assert torch.equal(probs[~same], pfl[~same])
 
 
 def test_margin_widens_itself_when_the_measured_error_approaches_it(case, gpu_device):
@@ -107,7 +123,7 @@ def test_margin_widens_itself_when_the_measured_error_approaches_it(case, gpu_de
     and needs no widening.  When the passes converged (the last one found nothing), every row that still keeps the f16
     arg-max has a margin of at least 1.5 x the largest error measured by the call."""
     from nesti_net_amd.model import NestiNet
-    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16, pfl, efl = case
     net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
     tau = 0.02                                                          # far below the f16 gate's error on this data (~0.1)
     net.set_gate_margin(tau)
@@ -121,7 +137,7 @@ def test_margin_widens_itself_when_the_measured_error_approaches_it(case, gpu_de
     assert st1["tau_eff"] == pytest.approx(1.5 * st1["max_margin_err"], rel=1e-6)
     # every row with an f16 margin below 1.5 x the error known when the widening round ran was decided by the f16x3 gate:
     # its outputs are f16x3's bit for bit; the others keep the f16 gate's (and may differ from f16x3 only through its error)
-    l16 = torch.log(p16.double())
+    l16 = torch.log(pfl.double())                                       # the filter pass's own logits (up to a shift)
     srt = torch.sort(l16, dim=1, descending=True).values
     margin16 = (srt[:, 0] - srt[:, 1]).cpu().numpy()                    # = the f16 logit margin (softmax is shift-invariant)
     decided_twice = (probs == ref[2]).all(dim=1).cpu().numpy()
@@ -148,8 +164,10 @@ def test_margin_widens_itself_when_the_measured_error_approaches_it(case, gpu_de
 
 def test_four_scale_filter_pass_reads_both_channel_groups(gpu_device):
     """n_scales = 4: the MuPS tensor has 80 channels = TWO 64-channel groups, which the pair layout stores as
-    [hi0 | lo0 | hi1 | lo1]; the plain-f16 filter pass must read hi0 and hi1 (ConvParams::in_chunk_bytes), not hi0 and lo0.
-    With tau = 0 the filter pass IS the whole gate, so its outputs must equal the plain-f16 model's gate bit for bit."""
+    [hi0 | lo0 | hi1 | lo1]; the filter pass must read hi0 and hi1 (ConvParams::in_chunk_bytes; its first layer runs the X2
+    loop on 32-channel chunks of the hi planes), not hi0 and lo0.  With tau = 0 the filter pass IS the whole gate: its
+    probabilities must sit within the filter's error of the f16x3 gate's -- closer than the plain-f16 model's gate, whose weights
+    are rounded -- while a wrong plane would feed 20 channels of rounding residue and land far away."""
     from nesti_net_amd import weights
     from nesti_net_amd.config import NestiConfig
     from nesti_net_amd.model import NestiNet
@@ -170,7 +188,12 @@ def test_four_scale_filter_pass_reads_both_channel_groups(gpu_device):
     assert net.mups_cstride == 2 * 128
     net.set_gate_margin(0.0)
     pc, ec = net.gate(net.mups(p, n))
-    assert torch.equal(pc, p16) and torch.equal(ec, e16)
+    x3g = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=Bq)
+    p3, e3 = x3g.gate(x3g.mups(p, n))
+    err_c, err_16 = float((pc - p3).abs().max().item()), float((p16 - p3).abs().max().item())
+    print("4-scale filter: prob err vs f16x3 %.4g (plain f16 gate %.4g)" % (err_c, err_16))
+    assert err_c <= max(err_16, 1e-3) and err_c < 0.02
+    del x3g
     # and scale 4 really reaches the gate: zeroing its patches changes the f16 probabilities
     pts0 = pts.copy()
     pts0[:, 3 * 128:] = 0
@@ -187,7 +210,7 @@ def test_product_path_batches_graph_and_stream_modes_agree(case, gpu_device):
     """nesti_estimate_normals with a ragged tail, the per-batch Python loop, a captured hipGraph and run_many: the same
     bits (each query's result depends on neither its batch nor its position in the flag list)."""
     from nesti_net_amd.pipeline import NormalEstimator
-    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16, pfl, efl = case
     sub = q[:2500]
     outs = []
     for kw in ({"batch": 2500}, {"batch": 1000}, {"batch": 1024, "use_graph": True}, {"batch": 900, "n_streams": 2}):
@@ -229,7 +252,7 @@ def test_gate_error_export_import_and_mix_switches(case, gpu_device):
     -- yet close -- result when a tap layer runs one product instead of three."""
     from nesti_net_amd import _lib
     from nesti_net_amd.model import NestiNet
-    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16 = case
+    cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16, pfl, efl = case
     net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=B)
     net.set_gate_margin(0.05)
     net.cascade_stats(reset=True)
