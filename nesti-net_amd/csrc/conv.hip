@@ -96,13 +96,14 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
   constexpr int kBTile = TN * kRowBytes;
   constexpr int kBVec = TN / 64;                  // 1-KiB pieces of a weight tile per wave
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
-  constexpr int kNA = KPIPE ? 2 : 1;              // A buffers
+  constexpr int kNA = X2 ? 3 : KPIPE ? 2 : 1;     // A buffers (X2: three stages of 32 + 16 KiB -- a 32-channel chunk is too short to
+                                                  // cover the fill latency with one chunk in flight)
   constexpr int kARow = X2 ? 64 : kRowBytes;      // bytes of one A row in LDS
   constexpr int kABuf = kTileM * kARow;           // one A buffer
   constexpr int kAPieces = kABuf / (8 * 1024);    // 1-KiB staging pieces per wave and chunk
   unsigned char* As = smem;
   unsigned char* Bs = smem + kNA * kABuf;
-  constexpr int kNB = KPIPE ? 2 : 4;              // weight-tile slots (general variant: 2 groups of 2 taps)
+  constexpr int kNB = X2 ? 3 : KPIPE ? 2 : 4;     // weight-tile slots (general variant: 2 groups of 2 taps)
   constexpr int kZeroOff = kNA * kABuf + kNB * kBTile;   // all-zero 128-B row (general variant only)
 
   const int tid = tid_in, lane = tid & 63;
@@ -134,9 +135,10 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
     const int slot = X2 ? (lane & 3) ^ ((row_l >> 2) & 3) : (lane & 7) ^ swz_key(row_l);   // inverse swizzle on the SOURCE
     // remap == 2: LDS row (block b, point pt) <- global row 8 pt + vox2(b)
     const long long gr = r0 + (remap == 2 ? ((row_l & 63) << 3) + vox2(row_l >> 6) : row_l);
-    if (gr < total_rows) {
-      long long pt = gr >> log2V;
-      const long long vox = gr & (V - 1);
+    if (gr < total_rows || X2) {                   // X2 counts its LDS-DMA instructions (s_waitcnt vmcnt(N)): a row beyond the live rows
+      const long long grs = gr < total_rows ? gr : r0;   // stages the tile's first row instead (its outputs are never stored)
+      long long pt = grs >> log2V;
+      const long long vox = grs & (V - 1);
       if (p.point_index) pt = p.point_index[pt];
       a_off[j] = (((pt << log2V) + vox) * p.in_cstride + p.in_coff) * kEsz +
                  (X3 ? (slot & 3) * 16 + (slot >> 2) * (2 * kSplitGroup) : slot * 16);
@@ -309,6 +311,32 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
     int a_addr[2], a_sw[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) { a_addr[mi] = rrow[mi] * kARow; a_sw[mi] = X2 ? (rrow[mi] >> 2) & 3 : swz_key(rrow[mi]); }
+    if constexpr (X2) {
+      // three stages, two chunks in flight: chunk c + 2 is issued right after the barrier that (a) publishes chunk c and (b) frees
+      // the buffer chunk c - 1 was multiplied from.  LDS-DMA completes in order and every wave issues exactly kPer instructions per
+      // chunk, so "chunk c has landed" is s_waitcnt vmcnt(kPer) while chunk c + 1 is still in flight (vmcnt(0) on the last chunk).
+      constexpr int kPer = kAPieces + kBVec;
+      stage_a(0, 0);
+      stage_b(0, 0, 0);
+      if (p.n_chunks > 1) {
+        stage_a(1, 1);
+        stage_b(1, 0, 1);
+      }
+      int cur = 0, nxt = 2;                          // buffers of chunk c and chunk c + 2
+      for (int c = 0; c < p.n_chunks; ++c) {
+        if (c + 1 < p.n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer) : "memory");
+        else wait_vm0();
+        __syncthreads();
+        if (c + 2 < p.n_chunks) {
+          stage_a(c + 2, nxt);
+          stage_b(c + 2, 0, nxt);
+        }
+        compute(true, true, As + cur * kABuf, Bs + cur * kBTile, a_addr, a_sw);
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt = nxt == 2 ? 0 : nxt + 1;
+      }
+      __syncthreads();                               // the epilogue reuses the LDS
+    } else {
     stage_a(0, 0);
     stage_b(0, 0, 0);
     wait_vm0();
@@ -326,6 +354,7 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
       compute(true, true, As + cur * kABuf, Bs + cur * kBTile, a_addr, a_sw);
       wait_vm0();
       __syncthreads();
+    }
     }
   } else {
     // ---- k^3 taps: A chunk resident, weight tiles double-buffered -----------------------------
