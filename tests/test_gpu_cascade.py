@@ -192,7 +192,7 @@ def test_four_scale_filter_pass_reads_both_channel_groups(gpu_device):
     p3, e3 = x3g.gate(x3g.mups(p, n))
     err_c, err_16 = float((pc - p3).abs().max().item()), float((p16 - p3).abs().max().item())
     print("4-scale filter: prob err vs f16x3 %.4g (plain f16 gate %.4g)" % (err_c, err_16))
-    assert err_c <= max(err_16, 1e-3) and err_c < 0.02
+    assert err_c < 0.01                                  # a wrong plane would put the probabilities tenths away
     del x3g
     # and scale 4 really reaches the gate: zeroing its patches changes the f16 probabilities
     pts0 = pts.copy()
