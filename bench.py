@@ -301,14 +301,17 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
             return sum(frac[e] * macs[(e, kind)][j] for e in range(E))
         return macs[(-1, kind)][j]
 
-    by_kernel, conv_ms, conv_n = {}, 0.0, 0
+    by_kernel, conv_ms, conv_n, issued_sum = {}, 0.0, 0, 0.0
     for k, name in enumerate(_lib.PROF_CONV):
         t_ms = sum(ms[ph][name] for ph in _lib.PROF_PHASES)
         n = sum(nl[ph][name] for ph in _lib.PROF_PHASES)
         conv_ms += t_ms
         conv_n += n
         alg = 2.0 * (per_pt(k, 1, "gate") + per_pt(k, 1, "experts")) * rank0_pts
-        issued = sum(2.0 * prod * per_pt(k, 2, "experts" if ph == "experts" else "gate") * q for ph, prod, q in phases)
+        # (f16x3c: the filter pass's one-tap layers multiply by the exact pair-packed weights -- two products per multiply)
+        issued = sum(2.0 * (2 if (dtype == "f16x3c" and ph == "gate" and name == "one_by_one_fc") else prod) *
+                     per_pt(k, 2, "experts" if ph == "experts" else "gate") * q for ph, prod, q in phases)
+        issued_sum += issued
         by_kernel[name] = {"ms_per_step": t_ms / steps, "launches_per_step": n / steps,
                            "algorithmic_gflop_per_query": alg / rank0_pts / 1e9,
                            "algorithmic_tflops": alg / (t_ms / 1e3) / 1e12 if t_ms else None,
@@ -319,7 +322,7 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
     if conv_s <= 0:          # nothing was recorded (e.g. every launch sat inside a replayed hipGraph)
         return None
     tot = [2.0 * (per_pt(-1, j, "gate") + per_pt(-1, j, "experts")) * rank0_pts / conv_s / 1e12 for j in range(3)]
-    issued_all = sum(2.0 * prod * per_pt(-1, 2, "experts" if ph == "experts" else "gate") * q for ph, prod, q in phases)
+    issued_all = issued_sum            # the classes partition the conv layers
     # HBM bytes per conv launch from the committed PMC passes of THIS configuration (FETCH_SIZE / WRITE_SIZE in
     # separate rocprofv3 runs of bench.py with the calibrated gate, gfx950-corrected: scripts/make_profiles.sh,
     # scripts/summarize_pmc.py).  Counters cannot be read from inside the process, so the figure is quoted from

@@ -41,12 +41,14 @@ extern "C" {
 enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16X3 = 4, NESTI_F16X3C = 5 };
 /* NESTI_F16X3C ("cascade", MODEL dtype only, gated models): everything that reaches the outputs is computed as in
  * NESTI_F16X3 -- the experts, and the gating net for every query whose decision could depend on it -- but the gating net
- * first runs in plain f16 as a FILTER: a query whose f16 top-2 logit margin is at least the gate margin tau keeps the f16
- * arg-max (a flip would need an f16 logit error of tau), every other query is decided again by the f16x3 gating net.
+ * first runs in plain f16 as a FILTER (plain f16 activations and tap layers; its 1x1x1 / FC layers, which are fill-bound, multiply
+ * by the exact pair-packed weights -- two products -- which halves the filter's error variance for a third more time in those
+ * layers): a query whose top-2 logit margin in that pass is at least the gate margin tau keeps its arg-max (a flip would need a
+ * filter error of tau), every other query is decided again by the f16x3 gating net.
  * expert_out / normals_out are then those of NESTI_F16X3 as long as the f16 gate's error on a logit difference stays below
  * the margin, which every call re-measures on the queries it decides twice and widens by itself when the measured error
- * comes within a factor NESTI_GATE_WIDEN of it (nesti_model_cascade_stats); probs_out carries the f16 gate's probabilities
- * (within ~0.02 of NESTI_F16X3's) for the queries that were not re-decided. */
+ * comes within a factor NESTI_GATE_WIDEN of it (nesti_model_cascade_stats); probs_out carries the filter pass's probabilities
+ * (within ~0.013 of NESTI_F16X3's) for the queries that were not re-decided. */
 
 /* which graph nesti_model_create builds */
 enum {

@@ -38,7 +38,7 @@ def build_parser():
                         "tolerance (arg-max exact up to fp32 ties, 1e-5 cosine) -- f16x3c for experts_n_est (f16 hi + lo pairs "
                         "behind the two-stage gate; its margin is calibrated on every shape and widens itself when the measured "
                         "error approaches it), f16x3 for the other models.  NOTE: with f16x3c the .experts_probs rows of queries "
-                        "the plain-f16 gate decided alone (~88 %%) are that gate's probabilities, within ~0.02 of the fp32 values; "
+                        "the filter pass decided alone (~90 %%) are that pass's probabilities, within ~0.013 of the fp32 values; "
                         "use --dtype f16x3 when the probabilities themselves must hold 1e-4.  f16 / bf16: plain 16-bit, ~1.7x "
                         "faster, hundreds of arg-max flips per 100k points (DESIGN.md 2); f32: the exact-fp32 MFMA mode")
     p.add_argument("--lib_batch", type=int, default=0,
