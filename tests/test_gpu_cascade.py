@@ -299,3 +299,29 @@ def test_gate_error_export_import_and_mix_switches(case, gpu_device):
     assert not torch.equal(pm, pg) and (pm - pg).abs().max().item() < 0.05 and (em != eg).float().mean().item() < 0.02
     with pytest.raises(_lib.NestiError, match="six bits"):
         x3.set_expert_mix(1 << 6)
+
+
+def test_cascade_on_the_3_gaussian_grid(gpu_device):
+    """--num_gaussians 3 with the two-stage gate: the filter pass's one-tap layers (conv1|conv4 of every block AND the k = 1 conv2
+    layers of inception3 / 4, all on the 3^3 grid embedded in 4^3) run the X2 loop; tau = inf must still be f16x3 bit for bit and
+    tau = 0 must land within the filter's error of it."""
+    from conftest import golden_patch_files, load_golden_patches
+    from nesti_net_amd import weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    cfg = NestiConfig(n_gaussians=3, gmm_variance=0.111)
+    W = weights.synthetic_weights(cfg)
+    g = load_golden_patches([p for p in golden_patch_files() if "ellipsoid20k" in p][0])
+    Bq = min(48, len(g["points"]))
+    p, n = torch.as_tensor(g["points"][:Bq], device=gpu_device), torch.as_tensor(g["n_eff"][:Bq], device=gpu_device)
+    x3 = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=Bq)
+    want = [t.clone() for t in x3(p, n)]
+    net = NestiNet(cfg, W, dtype="f16x3c", device=gpu_device, max_batch=Bq)
+    net.set_gate_margin(1e30)
+    for a, b in zip(net(p, n), want):
+        assert torch.equal(a, b)
+    net.set_gate_margin(0.0)
+    _, _, probs = net(p, n)
+    err = float((probs - want[2]).abs().max().item())
+    print("3^3 grid, filter alone: prob err vs f16x3 %.4g" % err)
+    assert err < 0.02 and net.cascade_stats()["rechecked"] == Bq        # the tau = inf call above rechecked everything, this one nothing more
