@@ -85,9 +85,10 @@ struct SwzKey {
 // and one set of fragment reads feeds three MFMAs (lo * W_hi, hi * W_hi, hi * W_lo): 1.5x the MFMAs per LDS byte, per
 // staged byte and per barrier of the plain kernel.
 // one (M tile, N tile) of the layer; `bid` is the position in the XCD-aware block order (blockIdx.x of a one-tile-per-workgroup launch)
-// X2 (kernels.h: ConvParams::x2; KPIPE, 16-bit, not X3): plain activations x pair-packed weights.  A K chunk is 32 channels: the A
-// rows are 64 B (16-B slot XOR-swizzled by (row >> 2) & 3, which makes the ds_read_b128 lane groups conflict-free on 64-byte rows),
-// the B rows are the pair packing's [W_hi k0..31 | W_lo k0..31]; per 16-channel K-step one A fragment set feeds hi * W_hi and hi * W_lo.
+// X2 (kernels.h: ConvParams::x2; KPIPE, 16-bit, not X3): plain activations x pair-packed weights.  The A side is the plain loop's:
+// 64-channel super-chunks, 128-byte rows (whole cache lines), two buffers.  The B side is the pair packing's: 32-channel chunks, rows
+// [W_hi k0..31 | W_lo k0..31], two buffers.  A 32-channel step h of super-chunk C reads the A fragments of slots 4 h .. 4 h + 3 and per
+// 16-channel K-step one A fragment set feeds hi * W_hi and hi * W_lo.
 template <int DT, int TN, bool KPIPE, bool X3, bool X2 = false>
 __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsigned bid, const int tid_in) {
   static_assert(!X2 || (KPIPE && !X3 && DT != NESTI_F32), "X2 is a 16-bit one-tap variant");
@@ -96,14 +97,14 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
   constexpr int kBTile = TN * kRowBytes;
   constexpr int kBVec = TN / 64;                  // 1-KiB pieces of a weight tile per wave
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
-  constexpr int kNA = X2 ? 3 : KPIPE ? 2 : 1;     // A buffers (X2: three stages of 32 + 16 KiB -- a 32-channel chunk is too short to
-                                                  // cover the fill latency with one chunk in flight)
-  constexpr int kARow = X2 ? 64 : kRowBytes;      // bytes of one A row in LDS
+  constexpr int kNA = KPIPE ? 2 : 1;              // A buffers
+  constexpr int kARow = kRowBytes;                // bytes of one A row in LDS (X2 too: the A side is staged in whole 128-byte lines --
+                                                  // 64-byte rows fetched every line twice and made the loop 68 % slower than plain)
   constexpr int kABuf = kTileM * kARow;           // one A buffer
   constexpr int kAPieces = kABuf / (8 * 1024);    // 1-KiB staging pieces per wave and chunk
   unsigned char* As = smem;
   unsigned char* Bs = smem + kNA * kABuf;
-  constexpr int kNB = X2 ? 3 : KPIPE ? 2 : 4;     // weight-tile slots (general variant: 2 groups of 2 taps)
+  constexpr int kNB = KPIPE ? 2 : 4;              // weight-tile slots (general variant: 2 groups of 2 taps)
   constexpr int kZeroOff = kNA * kABuf + kNB * kBTile;   // all-zero 128-B row (general variant only)
 
   const int tid = tid_in, lane = tid & 63;
@@ -130,9 +131,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
   long long a_off[kAPieces];
 #pragma unroll
   for (int j = 0; j < kAPieces; ++j) {
-    // X2: 64-byte rows -- a piece is 16 rows x 4 slots
-    const int row_l = X2 ? (wave * kAPieces + j) * 16 + (lane >> 2) : (wave * 8 + j) * 8 + (lane >> 3);
-    const int slot = X2 ? (lane & 3) ^ ((row_l >> 2) & 3) : (lane & 7) ^ swz_key(row_l);   // inverse swizzle on the SOURCE
+    const int row_l = (wave * 8 + j) * 8 + (lane >> 3);
+    const int slot = (lane & 7) ^ swz_key(row_l);   // inverse swizzle on the SOURCE
     // remap == 2: LDS row (block b, point pt) <- global row 8 pt + vox2(b)
     const long long gr = r0 + (remap == 2 ? ((row_l & 63) << 3) + vox2(row_l >> 6) : row_l);
     if (gr < total_rows || X2) {                   // X2 counts its LDS-DMA instructions (s_waitcnt vmcnt(N)): a row beyond the live rows
@@ -151,13 +151,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
       reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)n_tile * p.n_chunks * p.n_taps * kBTile;
 
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic segment
-  auto stage_a = [&](int c, int a_buf) __attribute__((always_inline)) {
+  auto stage_a = [&](int c, int a_buf, int j0 = 0, int j1 = kAPieces) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < kAPieces; ++j)
+    for (int j = j0; j < j1; ++j)
       if (a_off[j] >= 0)
-        glds16(in_b + a_off[j] + (X3   ? (long long)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (c & 1) * 64
-                                  : X2 ? (long long)(c >> 1) * p.in_chunk_bytes + (c & 1) * 64      // 32-channel chunk c of a plain / hi-plane row
-                                       : (long long)c * p.in_chunk_bytes),
+        glds16(in_b + a_off[j] + (X3 ? (long long)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (c & 1) * 64
+                                     : (long long)c * p.in_chunk_bytes),      // X2: c counts 64-channel SUPER-chunks here
                lds0 + a_buf * kABuf + (wave * kAPieces + j) * 1024);
   };
   auto stage_b = [&](int c, int t, int b_buf) __attribute__((always_inline)) {
@@ -248,8 +247,9 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
     if constexpr (X2) {
       // per 16-channel K-step t: one A fragment set (the lane's 16 B of the 64-byte row), W_hi and W_lo of the NI column tiles
       uint4 a0[2], a1[2], bh[NI], bl[NI];
+      const int xh = live0 ? 0 : 1;                // (the live0 argument carries the 32-channel half of the A super-chunk)
       auto ld_a = [&](int t, uint4 (&f)[2]) __attribute__((always_inline)) {
-        const int slot = t * 2 + khalf;
+        const int slot = xh * 4 + t * 2 + khalf;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) f[mi] = *reinterpret_cast<const uint4*>(Acur + a_addr[mi] + ((slot ^ a_sw[mi]) << 4));
       };
@@ -310,30 +310,28 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
     // ---- one tap: software pipeline over input-channel chunks --------------------------------
     int a_addr[2], a_sw[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) { a_addr[mi] = rrow[mi] * kARow; a_sw[mi] = X2 ? (rrow[mi] >> 2) & 3 : swz_key(rrow[mi]); }
+    for (int mi = 0; mi < 2; ++mi) { a_addr[mi] = rrow[mi] * kARow; a_sw[mi] = swz_key(rrow[mi]); }
     if constexpr (X2) {
-      // three stages, two chunks in flight: chunk c + 2 is issued right after the barrier that (a) publishes chunk c and (b) frees
-      // the buffer chunk c - 1 was multiplied from.  LDS-DMA completes in order and every wave issues exactly kPer instructions per
-      // chunk, so "chunk c has landed" is s_waitcnt vmcnt(kPer) while chunk c + 1 is still in flight (vmcnt(0) on the last chunk).
-      constexpr int kPer = kAPieces + kBVec;
+      // p.n_chunks counts the 32-channel weight chunks c = 2 C + h.  One barrier per chunk, at its top: it publishes B(c) (and, for
+      // h == 0, the A super-chunk C) and frees the buffers chunk c - 1 was multiplied from; right after it B(c + 1) goes to the other B
+      // buffer and, for h == 0, A(C + 1) to the other A buffer -- so the A side is two 32-channel steps ahead, the B side one.
+      // LDS-DMA completes in order and every wave issues the same number of instructions per stage (rows beyond the live rows stage
+      // the tile's first row), so at the top of an h == 1 chunk "B(c) has landed" is s_waitcnt vmcnt(kAPieces): only the A super-chunk
+      // issued after it may still be in flight; at the top of an h == 0 chunk everything issued must have landed.  (A(C + 1) is issued
+      // in two halves, one per step.)
       stage_a(0, 0);
       stage_b(0, 0, 0);
-      if (p.n_chunks > 1) {
-        stage_a(1, 1);
-        stage_b(1, 0, 1);
-      }
-      int cur = 0, nxt = 2;                          // buffers of chunk c and chunk c + 2
       for (int c = 0; c < p.n_chunks; ++c) {
-        if (c + 1 < p.n_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer) : "memory");
-        else wait_vm0();
+        const int h = c & 1, C = c >> 1;
+        if (h == 0 || c + 1 >= p.n_chunks) wait_vm0();       // (the last chunk's predecessor issued no A behind its B)
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAPieces / 2) : "memory");
         __syncthreads();
-        if (c + 2 < p.n_chunks) {
-          stage_a(c + 2, nxt);
-          stage_b(c + 2, 0, nxt);
-        }
-        compute(true, true, As + cur * kABuf, Bs + cur * kBTile, a_addr, a_sw);
-        cur = cur == 2 ? 0 : cur + 1;
-        nxt = nxt == 2 ? 0 : nxt + 1;
+#ifndef IGEMM_X2_NOFILL    // timing-only experiment (wrong results): the X2 K loop without its LDS fill
+        if (c + 1 < p.n_chunks) stage_b(c + 1, 0, (c + 1) & 1);
+        // the next A super-chunk in two halves, one per 32-channel step: every step then queues the same 48 KiB
+        if (c + 2 - h < p.n_chunks) stage_a(C + 1, (C + 1) & 1, h * (kAPieces / 2), (h + 1) * (kAPieces / 2));
+#endif
+        compute(h == 0, true, As + (C & 1) * kABuf, Bs + (c & 1) * kBTile, a_addr, a_sw);
       }
       __syncthreads();                               // the epilogue reuses the LDS
     } else {
