@@ -151,9 +151,9 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
       reinterpret_cast<const unsigned char*>(p.wpk) + (size_t)n_tile * p.n_chunks * p.n_taps * kBTile;
 
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;   // LDS byte address of the dynamic segment
-  auto stage_a = [&](int c, int a_buf, int j0 = 0, int j1 = kAPieces) __attribute__((always_inline)) {
+  auto stage_a = [&](int c, int a_buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = j0; j < j1; ++j)
+    for (int j = 0; j < kAPieces; ++j)
       if (a_off[j] >= 0)
         glds16(in_b + a_off[j] + (X3 ? (long long)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (c & 1) * 64
                                      : (long long)c * p.in_chunk_bytes),      // X2: c counts 64-channel SUPER-chunks here
@@ -317,19 +317,17 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
       // buffer and, for h == 0, A(C + 1) to the other A buffer -- so the A side is two 32-channel steps ahead, the B side one.
       // LDS-DMA completes in order and every wave issues the same number of instructions per stage (rows beyond the live rows stage
       // the tile's first row), so at the top of an h == 1 chunk "B(c) has landed" is s_waitcnt vmcnt(kAPieces): only the A super-chunk
-      // issued after it may still be in flight; at the top of an h == 0 chunk everything issued must have landed.  (A(C + 1) is issued
-      // in two halves, one per step.)
+      // issued after it may still be in flight; at the top of an h == 0 chunk everything issued must have landed.
       stage_a(0, 0);
       stage_b(0, 0, 0);
       for (int c = 0; c < p.n_chunks; ++c) {
         const int h = c & 1, C = c >> 1;
         if (h == 0 || c + 1 >= p.n_chunks) wait_vm0();       // (the last chunk's predecessor issued no A behind its B)
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAPieces / 2) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAPieces) : "memory");
         __syncthreads();
 #ifndef IGEMM_X2_NOFILL    // timing-only experiment (wrong results): the X2 K loop without its LDS fill
         if (c + 1 < p.n_chunks) stage_b(c + 1, 0, (c + 1) & 1);
-        // the next A super-chunk in two halves, one per 32-channel step: every step then queues the same 48 KiB
-        if (c + 2 - h < p.n_chunks) stage_a(C + 1, (C + 1) & 1, h * (kAPieces / 2), (h + 1) * (kAPieces / 2));
+        if (h == 0 && c + 2 < p.n_chunks) stage_a(C + 1, (C + 1) & 1);
 #endif
         compute(h == 0, true, As + (C & 1) * kABuf, Bs + (c & 1) * kBTile, a_addr, a_sw);
       }
