@@ -209,7 +209,8 @@ int nesti_model_set_expert_mix(nesti_model_t* m, int mask);
 /* The same switch for the gating net of a NESTI_F16X3 / NESTI_BF16X3 model (non-cascade nesti_gate_forward / nesti_forward):
  * on != 0 runs ALL its k^3 tap layers at 8^3 / 4^3 single-product, the 1x1x1 / FC layers stay three-product ("medium" gate);
  * on == 2 additionally rounds every layer's output to 16 bits (lo plane = 0): the numerics of a plain-f16 gate whose 1x1x1 / FC
- * layers multiply by the exact weights (hi * W_hi + hi * W_lo) -- the "exact-weight filter" of profiles/r05_gate_medium.txt. */
+ * layers multiply by the exact weights (hi * W_hi + hi * W_lo) -- the "exact-weight filter" of profiles/r05_gate_medium.txt; mode 2
+ * exists only in measurement builds (EXTRA_CXXFLAGS=-DNESTI_EXPERIMENT_XW), the product library refuses it. */
 int nesti_model_set_gate_mix(nesti_model_t* m, int on);
 
 /* Workspace of ONE tower for `batch` queries, from the configuration alone (no device needed): tower = -1 the gating

@@ -101,7 +101,9 @@ __device__ __forceinline__ void store_act4(unsigned char* base, long long row_el
   uint32_t h0, l0, h1, l1;
   split_pack2<E>(a, b, h0, l0);
   split_pack2<E>(c, d, h1, l1);
-  if (split == 2) l0 = l1 = 0u;      // experiment (model.hip: gate_mix == 2): the value rounded to 16 bits, as a pair with lo = 0
+#ifdef NESTI_EXPERIMENT_XW             // measurement builds only (model.hip: gate_mix == 2): the value rounded to 16 bits, lo = 0
+  if (split == 2) l0 = l1 = 0u;
+#endif
   unsigned char* d0 = base + (row_elems + split_col(col)) * 2;
   *reinterpret_cast<uint2*>(d0) = make_uint2(h0, h1);
   *reinterpret_cast<uint2*>(d0 + 2 * kSplitGroup) = make_uint2(l0, l1);
@@ -118,7 +120,9 @@ __device__ __forceinline__ void store_act8(unsigned char* base, long long row_el
   split_pack2<E>(f0.z, f0.w, h.y, l.y);
   split_pack2<E>(f1.x, f1.y, h.z, l.z);
   split_pack2<E>(f1.z, f1.w, h.w, l.w);
+#ifdef NESTI_EXPERIMENT_XW
   if (split == 2) l = make_uint4(0u, 0u, 0u, 0u);
+#endif
   unsigned char* d0 = base + (row_elems + split_col(col)) * 2;
   *reinterpret_cast<uint4*>(d0) = h;
   *reinterpret_cast<uint4*>(d0 + 2 * kSplitGroup) = l;

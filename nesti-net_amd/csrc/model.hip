@@ -1165,6 +1165,10 @@ int nesti_model_set_expert_mix(nesti_model_t* m, int mask) {
 int nesti_model_set_gate_mix(nesti_model_t* m, int on) {
   if (!m) NESTI_FAIL("nesti_model_set_gate_mix: null model");
   if (on && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_gate_mix: pair-mode experts_n_est models (8^3 grid) created after nesti_experiment_mix_enable(1) only");
+#ifndef NESTI_EXPERIMENT_XW
+  if (on == 2) NESTI_FAIL("nesti_model_set_gate_mix: mode 2 (the exact-weight filter emulation of profiles/r05_gate_medium.txt) needs a "
+                          "library built with EXTRA_CXXFLAGS=-DNESTI_EXPERIMENT_XW");
+#endif
   m->gate_mix = on == 2 ? 2 : on ? 1 : 0;   // 2: additionally every layer's OUTPUT is rounded to 16 bits (lo = 0): the numerics of a
                                             // plain-f16 gate whose 1x1x1 / FC layers multiply by the exact weights (hi * W_hi + hi * W_lo)
   return 0;

@@ -5,7 +5,9 @@ For every query of the bench cloud: logits (log of the probabilities; only diffe
 medium gate and the plain f16 gate.  Error of an approximate gate on the quantity the margin guards:
 err = max_k |(l_a - l_k)_approx - (l_a - l_k)_full|, a = the approximate gate's arg-max.  Reports sigma / max of both
 errors, the fraction of queries each threshold 1.5 x max would send on, the time of each pass, and the projected cost of
-filter -> medium -> full against today's filter -> full.  -> gpurun_out/gate_medium.txt"""
+filter -> medium -> full against today's filter -> full.  -> gpurun_out/gate_medium.txt
+The "xw" column (the numerics of a filter whose one-tap layers use the exact weights -- what round 5 then built as conv_igemm_kernel's
+X2 loop) needs a measurement build of the library: make -C nesti-net_amd/csrc clean all EXTRA_CXXFLAGS=-DNESTI_EXPERIMENT_XW."""
 import json
 import os
 import sys
