@@ -551,7 +551,8 @@ def main():
                                    "tau_over_max_margin_err": c["tau"] / c["max_margin_err"] if c["max_margin_err"] else None,
                                    "tau_eff_over_max_margin_err": c["tau_eff"] / c["max_margin_err"] if c["max_margin_err"] else None,
                                    "rounds_widened": c["widen_events"],
-                                   "note": "f16 filter pass over every query, f16x3 gate over those whose f16 top-2 logit margin "
+                                   "note": "f16 filter pass over every query (plain f16 activations and tap layers; its 1x1x1 / FC layers on the exact pair-packed "
+                                           "weights since round 5), f16x3 gate over those whose filter top-2 logit margin "
                                            "< tau_eff = max(tau, 1.5 x max_margin_err so far); max_margin_err = the f16 pass's largest "
                                            "error on a logit difference among the rechecked queries of the timed steps; when a call "
                                            "measures an error above tau_eff / 1.5 it re-decides the band up to 1.5 x that error in a "
