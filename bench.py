@@ -12,7 +12,7 @@ strong scaling) and prints it as "strong" in the same line.
 The headline dtype is f16x3c: every output is computed in f16 hi + lo pairs (three MFMA products per multiply, f16x3) and
 the gating net additionally runs in plain f16 first as a filter (NESTI_F16X3C, include/nesti_hip.h) -- the mode that
 meets the north star's parity clause (see "parity": every arg-max difference and the 1 - cos distribution against the
-exact-fp32 mode over the whole timed cloud).  The plain 16-bit mode ("fast_mode", f16) is 1.9x faster and does NOT meet it.
+exact-fp32 mode over the whole timed cloud).  The plain 16-bit mode ("fast_mode", f16) is 1.7x faster and does NOT meet it.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -598,16 +598,17 @@ def main():
                 # put the differing queries to the fp64 oracle (checker only)
                 adj = adjudicate_flips(cfg, W, clouds_np[0][0], res["parity"]["flip_rows"], main_run["shard0"], ref)
                 res["parity"]["adjudication"] = adj
-                # the oracle's gap is the authority on what a tie is (it is the rule tests/ hold the f32 mode itself to); it can
-                # only be trusted for the rows it saw (flip_rows is capped at 64)
+                # compare()'s own verdicts (the f32 mode's top-2 gap against TIE_MARGIN / 2e-5) stay as they are; the
+                # oracle's view is published under its own keys and can only ADD a condition: both the f32-mode gap and the
+                # fp64-oracle gap of every differing query must be inside the tie margin.  It is only trusted for the rows it saw
+                # (flip_rows is capped at 64)
                 seen_all = res["parity"]["argmax_flips"] <= len(adj["flips"])
-                cos_ok = res["parity"]["one_minus_cos"]["max"] <= res["parity"]["cos_tol"]
-                res["parity"]["meets_north_star"] = bool(cos_ok and seen_all and adj["all_ties"])
-                res["parity"]["meets_north_star_at_2e-5"] = bool(cos_ok and seen_all and adj["all_ties_at_2e-5"])
-                res["parity"]["verdict_rule"] = ("1 - cos <= cos_tol on every query whose arg-max agrees, and every arg-max difference "
-                                                 "is a query whose fp64-ORACLE top-2 gap is below tie_margin (meets_north_star) / "
-                                                 "below 2e-5 (meets_north_star_at_2e-5); flips_outside_margin / "
-                                                 "flips_gap_hand_to_margin count the same differences by the f32 mode's own gap")
+                res["parity"]["meets_north_star_oracle"] = bool(res["parity"]["meets_north_star"] and seen_all and adj["all_ties"])
+                res["parity"]["oracle_all_ties_at_2e-5"] = bool(seen_all and adj["all_ties_at_2e-5"])
+                res["parity"]["verdict_rule"] = ("meets_north_star: 1 - cos <= cos_tol on every query whose arg-max agrees and no arg-max "
+                                                 "difference where the f32 mode's own top-2 gap is >= tie_margin (meets_north_star_at_2e-5: "
+                                                 ">= 2e-5); meets_north_star_oracle additionally requires the fp64 ORACLE's top-2 gap of "
+                                                 "every differing query to be below tie_margin")
             # the exact-fp32 MFMA mode is the one the CPU oracle is tied to (tests/test_gpu_fixtures.py); its rate on the same
             # cloud, one untimed-style pass
             res["exact_mode"] = {"dtype": "f32", "value": ref_rate, "unit": "normals/sec (1 GPU, one pass over rank 0's shard)",

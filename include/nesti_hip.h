@@ -293,6 +293,19 @@ int nesti_estimate_normals_multi(const nesti_model_t* m, const nesti_shape_queri
                                  void* ws_dev, size_t ws_bytes, float* normals_out_dev, int32_t* expert_out_dev,
                                  float* probs_out_dev, void* stream);
 
+/* ---- the reference's own subsample stream, replayed on the host (refreplay.cpp) ----------
+ * utils/pcpnet_dataset.py:237-240, 320-321: ONE numpy RandomState(seed) shared by every patch and scale of every shape, one
+ * rng.choice(n, P, replace=False) per ball that holds n > P points, in visiting order (patch-major, scale-minor).  The stream
+ * object holds the MT19937 state between calls.  nesti_refstream_picks walks `n_balls` ball sizes in visiting order and writes,
+ * for every over-full ball, the P positions choice() returns (positions in cKDTree's traversal-ordered ball, uint16: balls of
+ * more than 65535 points are refused) at picks_out[offsets_out[b] .. + P); offsets_out[b] = -1 for a ball with n <= P (it draws
+ * nothing).  A call that fails leaves the stream untouched.  Host only; bit-identical to numpy (tests/test_refreplay.py). */
+typedef struct nesti_refstream nesti_refstream_t;
+nesti_refstream_t* nesti_refstream_create(uint32_t seed);
+void nesti_refstream_destroy(nesti_refstream_t* s);
+int nesti_refstream_picks(nesti_refstream_t* s, const int32_t* sizes, int64_t n_balls, int P, uint16_t* picks_out,
+                          int64_t picks_capacity, int64_t* offsets_out, int64_t* n_over_out);
+
 /* ---- text I/O of the file seam (host only) ------------------------------------------------
  * Reading stays np.loadtxt (utils/pcpnet_dataset.py:250): numpy 2's parser is faster than a strtod loop, and the
  * .npy cache the reference writes next to the file makes it a one-off.  The writers are native: np.savetxt's

@@ -83,6 +83,9 @@ SIGNATURES = {
     "nesti_write_text_f32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64, _i]),
     "nesti_write_text_i32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64]),
     "nesti_estimate_normals_multi": (_i, [_vp, ctypes.POINTER(CShapeQueries), _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "nesti_refstream_create": (_vp, [ctypes.c_uint32]),
+    "nesti_refstream_destroy": (None, [_vp]),
+    "nesti_refstream_picks": (_i, [_vp, _vp, ctypes.c_int64, _i, _vp, ctypes.c_int64, _vp, ctypes.POINTER(ctypes.c_int64)]),
     "nesti_profile_enable": (_i, [_i]),
     "nesti_profile_read": (_i, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong)]),
     "nesti_model_macs": (_i, [_vp, _i, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
@@ -123,6 +126,10 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
+    ver = (lib.nesti_version() or b"").decode()
+    if "TIMING-EXPERIMENTS" in ver and os.environ.get("NESTI_ALLOW_TIMING_BUILD") != "1":
+        raise NestiError("%s is a timing-only build (%s): it computes wrong results on purpose; set NESTI_ALLOW_TIMING_BUILD=1 "
+                         "to load it for a measurement" % (LIB_PATH, ver))
     _lib = lib
     return lib
 

@@ -7,6 +7,15 @@
 
 #include "../../include/nesti_hip.h"
 
+// Timing-only switches (conv.hip: IGEMM_X2_NOFILL / IGEMM_NO_MAIN / IGEMM_EMPTY / IGEMM_NO_EPILOGUE / IGEMM_NO_STORE, conv8n.hip:
+// CONV8N_DOUBLE_MMA) build a library that computes WRONG results on purpose (they time one phase of a kernel).  They exist only
+// behind ONE guard: a build that sets any of them without -DNESTI_TIMING_EXPERIMENTS does not compile, and a build with the guard
+// says so in nesti_version(), which nesti-net_amd/_lib.py refuses to load unless NESTI_ALLOW_TIMING_BUILD=1 is set.
+#if !defined(NESTI_TIMING_EXPERIMENTS) && (defined(IGEMM_X2_NOFILL) || defined(IGEMM_NO_MAIN) || defined(IGEMM_EMPTY) || \
+                                          defined(IGEMM_NO_EPILOGUE) || defined(IGEMM_NO_STORE) || defined(CONV8N_DOUBLE_MMA))
+#error "timing-only switches need -DNESTI_TIMING_EXPERIMENTS (the resulting library computes wrong results and says so in nesti_version())"
+#endif
+
 namespace nesti {
 
 void set_error(const std::string& msg);

@@ -1009,7 +1009,20 @@ using namespace nesti;
 extern "C" {
 
 const char* nesti_last_error(void) { return g_error.c_str(); }
-const char* nesti_version(void) { return "nesti-hip 0.5 (gfx950)"; }
+const char* nesti_version(void) {
+  // _lib.py refuses a library whose version string contains "TIMING-EXPERIMENTS" (common.h); measurement builds are named too
+  return "nesti-hip 0.6 (gfx950)"
+#ifdef NESTI_TIMING_EXPERIMENTS
+         " TIMING-EXPERIMENTS build: WRONG RESULTS by construction"
+#endif
+#ifdef NESTI_ATTRIBUTION
+         " [measurement build: NESTI_ATTRIBUTION]"
+#endif
+#ifdef NESTI_EXPERIMENT_XW
+         " [measurement build: NESTI_EXPERIMENT_XW]"
+#endif
+      ;
+}
 
 void nesti_default_config(nesti_config_t* cfg) {
   memset(cfg, 0, sizeof(*cfg));

@@ -27,6 +27,46 @@ if scipy_version < (1, 6):
     raise ImportError("nesti_net_amd.refsample needs scipy >= 1.6 (query_ball_point return_sorted / workers), found %s" % scipy.__version__)
 
 
+class RefStream:
+    """The reference's shared random stream replayed natively (``csrc/refreplay.cpp``: MT19937 + numpy's legacy shuffle,
+    bit-identical to ``RandomState(seed).choice(n, P, replace=False)`` ball after ball -- tests/test_refreplay.py).  Feeds the
+    GPU reference-order path: ball sizes in, pick table out; only over-full balls draw (``utils/pcpnet_dataset.py:320-321``)."""
+
+    def __init__(self, seed=REFERENCE_SEED):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        self.lib = _lib.load()
+        self._h = ctypes.c_void_p(self.lib.nesti_refstream_create(int(seed) & 0xffffffff))
+        if not self._h.value:
+            raise _lib.NestiError("nesti_refstream_create failed")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                self.lib.nesti_refstream_destroy(self._h)
+                self._h.value = None
+        except Exception:      # interpreter shutdown
+            pass
+
+    def picks(self, sizes, P, out=None):
+        """``sizes``: int32 ball sizes in visiting order (patch-major, scale-minor).  Returns (picks uint16 [n_over * P],
+        offsets int64 [len(sizes)], -1 where the ball holds <= P points).  ``out``: optional (picks, offsets) buffers to fill
+        (picks at least ``count(sizes > P) * P`` long), e.g. pinned host tensors' numpy views."""
+        sizes = np.ascontiguousarray(sizes, dtype=np.int32).ravel()
+        n_over = int((sizes > P).sum())
+        if out is None:
+            picks, offsets = np.empty(n_over * P, np.uint16), np.empty(len(sizes), np.int64)
+        else:
+            picks, offsets = out
+            if picks.dtype != np.uint16 or offsets.dtype != np.int64 or len(offsets) < len(sizes) or not picks.flags.c_contiguous:
+                raise ValueError("out = (uint16 picks, int64 offsets[len(sizes)])")
+        got = self._ct.c_int64(0)
+        self._lib.check(self.lib.nesti_refstream_picks(self._h, self._lib.ptr(sizes), len(sizes), int(P), self._lib.ptr(picks), picks.size,
+                                                       self._lib.ptr(offsets), self._ct.byref(got)), "nesti_refstream_picks")
+        return picks[:got.value * P], offsets[:len(sizes)]
+
+
 class ReferencePatchSampler:
     """Holds the random stream of one reference ``PointcloudPatchDataset`` (``utils/pcpnet_dataset.py:237-240``).
     Patches must be requested in the reference's visiting order (shapes in list order, patch rows in order,
