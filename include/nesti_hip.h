@@ -38,7 +38,7 @@ extern "C" {
  * bf16 pairs hold 2^-17 relative; f16 pairs hold max(2^-23 relative, 3e-8 absolute) with the weights of each layer scaled
  * by a power of two into f16's normal range (undone in the epilogue): the mode that keeps test_n_est_w_experts.py's outputs
  * within the 1e-5 cosine / arg-max tolerance with two orders of magnitude to spare. */
-enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16X3 = 4, NESTI_F16X3C = 5 };
+enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16X3 = 4, NESTI_F16X3C = 5, NESTI_F16X8 = 6, NESTI_F16X8C = 7 };
 /* NESTI_F16X3C ("cascade", MODEL dtype only, gated models): everything that reaches the outputs is computed as in
  * NESTI_F16X3 -- the experts, and the gating net for every query whose decision could depend on it -- but the gating net
  * first runs in plain f16 as a FILTER (plain f16 activations and tap layers; its 1x1x1 / FC layers, which are fill-bound, multiply
@@ -49,6 +49,19 @@ enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16
  * the margin, which every call re-measures on the queries it decides twice and widens by itself when the measured error
  * comes within a factor NESTI_GATE_WIDEN of it (nesti_model_cascade_stats); probs_out carries the filter pass's probabilities
  * (within ~0.013 of NESTI_F16X3's) for the queries that were not re-decided. */
+
+/* NESTI_F16X8 / NESTI_F16X8C (round 6; MODEL dtypes only, experts_n_est on the 8^3 grid): NESTI_F16X3 / NESTI_F16X3C with the two
+ * CROSS terms of the pair scheme -- lo * W_hi + hi * W_lo, 2^-11 of a layer's result -- of the EXPERT towers' 5^3 tap layers at 8^3
+ * (models/experts_n_est.py:258-262: conv3 of inception1 / inception2, 2/3 of an expert's multiply-accumulates) computed by one
+ * block-scaled FP8 MFMA (e4m3 x e4m3, K = 64, fp32 accumulate into the same accumulator) instead of four f16 MFMAs; hi * W_hi stays
+ * an exact f16 product.  The gating net -- filter AND recheck -- is untouched, so expert_out is NESTI_F16X3C's bit for bit; the
+ * normals differ from NESTI_F16X3's by a residual 28x below single-product f16: max 1 - cos 1.1e-6 over the bench's 100 000
+ * queries in the emulation that preceded the kernel (profiles/r06_fp8_cross_step0.txt), against the 1e-5 tolerance.  The e4m3
+ * planes' power-of-two pre-scales come from the producing layer's folded batch-norm (|beta| + 8 |gamma|: a data-free bound on its
+ * activations; larger values saturate at the format's 448 and lose only their own cross terms).
+ * nesti_model_set_x8_layers picks the layers: bit 0 / 1 = inception1 conv2 (3^3) / conv3 (5^3), bit 2 / 3 = inception2 conv2 / conv3;
+ * the default is 0b1010 (both 5^3 layers), 0 is NESTI_F16X3 proper.  With the 3^3 layers too the emulation's worst query reaches
+ * 3.5e-6.  Must not be changed while forward calls are in flight (declared below: nesti_model_set_x8_layers). */
 
 /* which graph nesti_model_create builds */
 enum {
@@ -142,6 +155,30 @@ int nesti_patches_build(const nesti_config_t* cfg, const float* cloud_dev, int N
                         int32_t* n_ball_out_dev, void* grid_ws_dev, size_t grid_ws_bytes,
                         void* stream);
 
+/* ---- the reference's own subsample ORDER on the GPU (utils/pcpnet_dataset.py:304, 320-321) ----------------------------------
+ * When a ball holds n > P points the reference keeps ball[rng.choice(n, P, replace=False)] of cKDTree's traversal-ordered ball.
+ * query_ball_point returns a ball in ascending position in tree.indices, so the order is a sort key and the random stream only
+ * needs the ball sizes:
+ *   nesti_patches_count      n_ball_out_dev[M, S] = ball sizes of the queries (the count pass; nothing else is written);
+ *   nesti_refstream_picks    (host, below) replays the shared RandomState over those sizes in visiting order -> pick table;
+ *   nesti_patches_query_ref  the patch tensors exactly as PointcloudPatchDataset.__getitem__ builds them: per query the points
+ *                            inside the largest ball are sorted in LDS by tree_rank_dev[i] (= position of point i in
+ *                            tree.indices; tree_order_dev = tree.indices itself, both int32 [N], built on the host with
+ *                            scipy.spatial.cKDTree(pts, 10) like utils/pcpnet_dataset.py:37), each scale's ball is taken in
+ *                            that order, n <= P: as it is, rows beyond n zero; n > P: ball[picks] with the P uint16 picks at
+ *                            picks_dev[pick_offsets_dev[q * S + s]] (offset -1: the ball holds <= P points).
+ * A ball of more than nesti_patches_ref_max_ball() points does not fit the LDS sort: its n_eff comes back as -1 and its rows
+ * zero -- callers hold the counts and must refuse such a shape before the launch (provider.CloudPatches does). */
+int nesti_patches_count(const nesti_config_t* cfg, const float* cloud_dev, int N, const int32_t* query_idx_dev, int M,
+                        const double* r_abs, int query_row0, int32_t* n_ball_out_dev, const void* grid_ws_dev,
+                        size_t grid_ws_bytes, void* stream);
+int nesti_patches_ref_max_ball(void);
+int nesti_patches_query_ref(const nesti_config_t* cfg, const float* cloud_dev, int N, const int32_t* query_idx_dev, int M,
+                            const double* r_abs, int query_row0, const int32_t* tree_rank_dev, const int32_t* tree_order_dev,
+                            const uint16_t* picks_dev, const int64_t* pick_offsets_dev, float* points_out_dev,
+                            int32_t* n_eff_out_dev, int32_t* nbr_idx_out_dev, const void* grid_ws_dev, size_t grid_ws_bytes,
+                            void* stream);
+
 /* Enumerate the variables the graph for cfg expects (names follow the reference's
  * scopes, models/experts_n_est.py:155-314).  Call with infos=NULL to get the count. */
 int nesti_model_describe(const nesti_config_t* cfg, int* n_tensors, nesti_tensor_t* infos,
@@ -212,6 +249,9 @@ int nesti_model_set_expert_mix(nesti_model_t* m, int mask);
  * layers multiply by the exact weights (hi * W_hi + hi * W_lo) -- the "exact-weight filter" of profiles/r05_gate_medium.txt; mode 2
  * exists only in measurement builds (EXTRA_CXXFLAGS=-DNESTI_EXPERIMENT_XW), the product library refuses it. */
 int nesti_model_set_gate_mix(nesti_model_t* m, int on);
+/* NESTI_F16X8 / NESTI_F16X8C models: which expert tap layers at 8^3 take their cross terms through FP8 (see the dtype's comment above;
+ * default 0b1010, 0 = NESTI_F16X3 proper, at most 0b1111). */
+int nesti_model_set_x8_layers(nesti_model_t* m, int mask);
 
 /* Workspace of ONE tower for `batch` queries, from the configuration alone (no device needed): tower = -1 the gating
  * net, 0..E-1 an expert.  dtype as nesti_model_create (NESTI_F16X3C: the gate figure is the f16 filter's). */

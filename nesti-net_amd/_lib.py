@@ -58,6 +58,10 @@ SIGNATURES = {
                                  _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "nesti_patches_build": (_i, [_cfgp, _vp, _i, _vp, _i, ctypes.POINTER(ctypes.c_double), _u64, _i,
                                  _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "nesti_patches_count": (_i, [_cfgp, _vp, _i, _vp, _i, ctypes.POINTER(ctypes.c_double), _i, _vp, _vp, _sz, _vp]),
+    "nesti_patches_ref_max_ball": (_i, []),
+    "nesti_patches_query_ref": (_i, [_cfgp, _vp, _i, _vp, _i, ctypes.POINTER(ctypes.c_double), _i, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, _sz, _vp]),
     "nesti_model_describe": (_i, [_cfgp, ctypes.POINTER(_i), ctypes.POINTER(CTensor), _i]),
     "nesti_model_create": (_i, [_cfgp, ctypes.POINTER(CTensor), _i, _i, ctypes.POINTER(_vp)]),
     "nesti_model_destroy": (None, [_vp]),
@@ -68,6 +72,7 @@ SIGNATURES = {
     "nesti_experiment_mix_enable": (_i, [_i]),
     "nesti_model_set_expert_mix": (_i, [_vp, _i]),
     "nesti_model_set_gate_mix": (_i, [_vp, _i]),
+    "nesti_model_set_x8_layers": (_i, [_vp, _i]),
     "nesti_tower_workspace_bytes": (_sz, [_cfgp, _i, _i, _i]),
     "nesti_workspace_bytes": (_sz, [_vp, _i]),
     "nesti_model_mups_cstride": (_i, [_vp]),

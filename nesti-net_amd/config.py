@@ -7,7 +7,9 @@ from typing import Dict, List
 
 MAX_SCALES = 4
 MAX_EXPERTS = 8
-DTYPES = {"f32": 0, "bf16": 1, "f16": 2, "bf16x3": 3, "f16x3": 4, "f16x3c": 5}   # include/nesti_hip.h: NESTI_F32 ... NESTI_F16X3C
+DTYPES = {"f32": 0, "bf16": 1, "f16": 2, "bf16x3": 3, "f16x3": 4, "f16x3c": 5, "f16x8": 6, "f16x8c": 7}   # include/nesti_hip.h: NESTI_F32 ... NESTI_F16X8C
+CASCADE_DTYPES = ("f16x3c", "f16x8c")     # the two-stage gate (gate margin, cascade statistics)
+PAIR_DTYPES = ("f16x3", "bf16x3", "f16x3c", "f16x8", "f16x8c")   # activations as 16-bit (hi, lo) pairs
 ARCH_EXPERTS, ARCH_SINGLE, ARCH_MULTI, ARCH_SWITCH = 0, 1, 2, 3
 SWITCH_NOISE_THRESHOLD = 0.015   # models/ms_sw_n_est.py:80
 

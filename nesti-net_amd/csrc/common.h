@@ -41,7 +41,9 @@ static inline size_t dtype_size(int dt) { return dt == NESTI_F32 ? 4 : 2; }
 // and one set of fragment reads feeds hi*W_hi + lo*W_hi + hi*W_lo.  Writers emit the planes (split_col / split_pack2 below).
 // NESTI_F16X3: the same with f16 pairs and the f16 kernels.
 // NESTI_F16X3C is NESTI_F16X3 everywhere except in the gating net's first pass (model.hip: gate_cascade)
-static inline int main_dtype(int dt) { return dt == NESTI_F16X3C ? NESTI_F16X3 : dt; }
+static inline int main_dtype(int dt) { return (dt == NESTI_F16X3C || dt == NESTI_F16X8 || dt == NESTI_F16X8C) ? NESTI_F16X3 : dt; }
+static inline bool dtype_cascade(int dt) { return dt == NESTI_F16X3C || dt == NESTI_F16X8C; }
+static inline bool dtype_x8(int dt) { return dt == NESTI_F16X8 || dt == NESTI_F16X8C; }
 static inline int kernel_dtype(int dt) { return dt == NESTI_BF16X3 ? NESTI_BF16 : dt == NESTI_F16X3 ? NESTI_F16 : dt; }
 constexpr int kPairPlanes = 2;    // hi, lo
 static inline int act_planes(int dt) { return (dt == NESTI_BF16X3 || dt == NESTI_F16X3) ? kPairPlanes : 1; }
@@ -135,6 +137,30 @@ __device__ __forceinline__ void store_act8(unsigned char* base, long long row_el
   unsigned char* d0 = base + (row_elems + split_col(col)) * 2;
   *reinterpret_cast<uint4*>(d0) = h;
   *reinterpret_cast<uint4*>(d0 + 2 * kSplitGroup) = l;
+}
+
+// ---- e4m3 planes of the FP8 cross terms (kernels.h: ConvParams::aux8_out; conv8n.hip X8) ----------------------------------------
+// Four values -> four OCP e4m3 bytes (v_cvt_pk_fp8_f32: round to nearest even, subnormals kept), saturated at +-448 (the
+// conversion itself would produce NaN above the format's range).
+__device__ __forceinline__ uint32_t pack4_e4m3(float a, float b, float c, float d) {
+  a = __builtin_amdgcn_fmed3f(a, -448.f, 448.f); b = __builtin_amdgcn_fmed3f(b, -448.f, 448.f);
+  c = __builtin_amdgcn_fmed3f(c, -448.f, 448.f); d = __builtin_amdgcn_fmed3f(d, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
+}
+// The side-buffer row of one activation row: per 64-channel group [lo8 64 B | hi8 64 B]; `col` = logical column (multiple of 4),
+// v = the activated fp32 values, hi = f16(v): lo8 = e4m3((v - hi) mul_lo), hi8 = e4m3(v mul_hi), mul_* = the layer's power-of-two pre-scales.
+__device__ __forceinline__ void store_aux8_4(unsigned char* aux_row, int col, float a, float b, float c, float d, float mul_lo, float mul_hi) {
+  const float ha = f16_bits_to_f32(f32_to_f16_bits(a)), hb = f16_bits_to_f32(f32_to_f16_bits(b));
+  const float hc = f16_bits_to_f32(f32_to_f16_bits(c)), hd = f16_bits_to_f32(f32_to_f16_bits(d));
+  unsigned char* dst = aux_row + (col >> 6) * (2 * kSplitGroup) + (col & (kSplitGroup - 1));
+  *reinterpret_cast<uint32_t*>(dst) = pack4_e4m3((a - ha) * mul_lo, (b - hb) * mul_lo, (c - hc) * mul_lo, (d - hd) * mul_lo);
+  *reinterpret_cast<uint32_t*>(dst + kSplitGroup) = pack4_e4m3(a * mul_hi, b * mul_hi, c * mul_hi, d * mul_hi);
+}
+__device__ __forceinline__ void store_aux8_8(unsigned char* aux_row, int col, const float4& f0, const float4& f1, float mul_lo, float mul_hi) {
+  store_aux8_4(aux_row, col, f0.x, f0.y, f0.z, f0.w, mul_lo, mul_hi);
+  store_aux8_4(aux_row, col + 4, f1.x, f1.y, f1.z, f1.w, mul_lo, mul_hi);
 }
 
 // the pair modes as store types (mups.hip): 16-bit elements, two planes

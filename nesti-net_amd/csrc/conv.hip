@@ -424,6 +424,8 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
   const int out_col0 = (second ? p.out_coff2 : p.out_coff) + n_local * TN;
   const float* bias = p.bias + n_tile * TN;
   const float act_floor = p.relu ? 0.f : -INFINITY;      // ReLU as one v_max
+  // kernels.h: ConvParams::aux8_out -- power-of-two pre-scales of the e4m3 planes (exact multiplications)
+  const float aux_mul_lo = __builtin_ldexpf(1.f, p.x8_sa), aux_mul_hi = __builtin_ldexpf(1.f, p.x8_sc);
 
   if (KPIPE && second && p.pool_k > 1) {
     // avg_pool3d(k, SAME, stride 1) of the pre-activation: per 64-column half the fp32 accumulators go
@@ -628,9 +630,13 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
           const int item = it * kThreads + tid;
           const int row = item >> 4, cg = item & 15;
           const long long gr = r0 + row;
-          if (gr < total_rows)
-            cvt_store(out_b, gr * p.out_cstride, out_col0 + nh * 64 + cg * 4,
-                      *reinterpret_cast<const float4*>(smem + row * kPoolStride + cg * 16));
+          if (gr < total_rows) {
+            const float4 v4 = *reinterpret_cast<const float4*>(smem + row * kPoolStride + cg * 16);
+            cvt_store(out_b, gr * p.out_cstride, out_col0 + nh * 64 + cg * 4, v4);
+            if (p.aux8_out)       // the e4m3 planes of conv1's outputs for the FP8 cross terms of the block's tap layers (conv8n.hip X8)
+              store_aux8_4(reinterpret_cast<unsigned char*>(p.aux8_out) + gr * p.aux8_stride, n_local * TN + nh * 64 + cg * 4,
+                           v4.x, v4.y, v4.z, v4.w, aux_mul_lo, aux_mul_hi);
+          }
         }
       }
 #pragma unroll
@@ -693,7 +699,12 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
           const float4 f0 = *reinterpret_cast<const float4*>(scratch + row * kPoolStride + cpos * 32);
           const float4 f1 = *reinterpret_cast<const float4*>(scratch + row * kPoolStride + cpos * 32 + 16);
           const long long gr = r0 + tile_row(remap, log2S, wave, mi, row);
-          if (gr < total_rows) store_act8<E>(out_b, gr * p.out_cstride, out_col0 + nh * 64 + cpos * 8, f0, f1, p.split);
+          if (gr < total_rows) {
+            store_act8<E>(out_b, gr * p.out_cstride, out_col0 + nh * 64 + cpos * 8, f0, f1, p.split);
+            if (p.aux8_out && !second)
+              store_aux8_8(reinterpret_cast<unsigned char*>(p.aux8_out) + gr * p.aux8_stride, n_local * TN + nh * 64 + cpos * 8, f0, f1,
+                           aux_mul_lo, aux_mul_hi);
+          }
         }
       }
     }

@@ -43,6 +43,17 @@
 // activation pair (staged from the two planes of the [hi 64 | lo 64] row groups) and a weight row [W_hi k0..15 | W_lo k0..15]
 // -- and a tap multiplies hi * W_hi + lo * W_hi + hi * W_lo from ONE set of fragment reads.
 //
+// X8 (round 6, NESTI_F16X8 / NESTI_F16X8C, the experts' tap layers picked by nesti_model::x8_mask): the two CROSS terms of the pair
+// scheme carry 2^-11 of the result, so they go through ONE block-scaled FP8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3, same fp32
+// accumulators) instead of two f16 MFMAs each: an LDS row is [hi k0..15 f16 | lo8 k0..15 | hi8 k0..15] (hi from the pair buffer's hi
+// plane, the two e4m3 planes from the side buffer the producing 1x1x1 layer writes: conv.hip, ConvParams::aux8_out), a weight row
+// [W_hi f16 | W_hi8 | W_lo8], and the K = 64 of one FP8 instruction is TWO taps x [lo8 | hi8]: lanes 0-31 (K block 0) read tap u's
+// rows, lanes 32-63 (K block 1) tap u + 1's -- a per-lane address like the x shift itself.  Per tap and (tile, column tile): one f16
+// MFMA (hi * W_hi, exact products) and, every second tap (and at the odd tap that ends a row, its second K block reading zeros), one
+// FP8 MFMA: lo8 * W_hi8 + hi8 * W_lo8 with the E8M0 block scales 2^-sa, 2^-sb undoing the power-of-two pre-scales.  Measured before it
+// was built (profiles/r06_fp8_cross_step0.txt, r06_x8_ubench.txt): the residual is 28x below single-product f16 (max 1 - cos 1.1e-6
+// over the bench cloud with both 5^3 layers of every expert in this form) at 1.47x the pair loop's multiply rate.
+//
 // What did NOT pay (profiles/r02_conv8_experiments.txt): seven re-schedulings of this loop -- waves out of
 // phase, counted vmcnt, hand-counted lgkmcnt with inline-asm reads, adjacent MFMA pairs, K-step-major order, weights straight
 // from L2 into registers without a row barrier, barrier-free rows through LDS counters -- all within +-3 % or slower.  The
@@ -77,8 +88,12 @@ __device__ __forceinline__ uint4 lds128n(unsigned addr) {
 
 template <int K> constexpr int lds_bytes_n() { return kAOffN + 8 * (4 + (K - 1) / 2) * kTileN; }
 
-template <int DT, int K, bool X3>
+typedef int i32x8n_t __attribute__((ext_vector_type(8)));
+
+template <int DT, int K, int MODE>     // MODE 0: plain, 1: the pair K loop (X3), 2: f16 hi * W_hi + FP8 cross terms (X8)
 __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned bid, const int tid_in) {
+  constexpr bool X3 = MODE == 1, X8 = MODE == 2;
+  static_assert(!X8 || DT == NESTI_F16, "the FP8 cross-term loop is an f16 pair-mode variant");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
   constexpr int LO = (K - 1) / 2;
@@ -120,23 +135,38 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
   const int st_row = lane >> 2;
   unsigned a_voff[2];
   bool a_ok[2];
+  bool a_is8[2];                                        // X8: this lane's 16-B slot comes from the side buffer (slot 2: its lo8
+  const unsigned char* aux_b = nullptr;                  // plane, slot 3: its hi8 plane) instead of the pair buffer's hi plane (slots 0, 1)
+  if constexpr (X8) aux_b = reinterpret_cast<const unsigned char*>(p.aux8_in) + (size_t)p0 * 512 * p.aux8_stride;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int pt = 2 * h + (st_row >> 3), x = st_row & 7;
     const int kslot = (lane & 3) ^ pt;                   // inverse swizzle on the SOURCE (LDS-DMA writes lane-linear)
     a_voff[h] = (unsigned)((pt * 512 + x) * p.in_cstride * kEsz + (X3 ? (kslot & 1) * 16 + (kslot >> 1) * (2 * kSplitGroup) : kslot * 16));
+    a_is8[h] = X8 && kslot >= 2;
+    if (a_is8[h]) a_voff[h] = (unsigned)((pt * 512 + x) * p.aux8_stride + (kslot - 2) * kSplitGroup);
     a_ok[h] = pt < np_here;
   }
   auto stage_a = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
     for (int jz = 0; jz < NZ; ++jz) {
       const int zp = zlo + jz, yp = (wave - zp) & 7;     // source tile (y', z') of this wave's run: (y' + z') & 7 == wave
+      if constexpr (X8) {
+        // chunk c = 16 channels: the hi plane of the pair row group [hi 64 | lo 64] (32 B at (c & 3) * 32) and 16 B of each e4m3
+        // plane of the side row group [lo8 64 | hi8 64]
+        const size_t off16 = (size_t)((zp * 64 + yp * 8) * p.in_cstride) * kEsz + (size_t)(c >> 2) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 3) * 32;
+        const size_t off8 = (size_t)(zp * 64 + yp * 8) * p.aux8_stride + (size_t)(c >> 2) * (2 * kSplitGroup) + (size_t)(c & 3) * 16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (a_ok[h]) glds16((a_is8[h] ? aux_b + off8 : in_b + off16) + a_voff[h], lds0 + kAOffN + (wave * NZ + jz) * kTileN + h * 1024);
+      } else {
       const unsigned char* src = in_b + (size_t)((zp * 64 + yp * 8) * p.in_cstride) * kEsz +
                                  (X3 ? (size_t)(c >> 2) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 3) * 32
                                      : p.in_pair ? (size_t)(c >> 1) * (2 * kPairPlanes * kSplitGroup) + (size_t)(c & 1) * 64 : (size_t)c * 64);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
         if (a_ok[h]) glds16(src + a_voff[h], lds0 + kAOffN + (wave * NZ + jz) * kTileN + h * 1024);
+      }
     }
   };
   auto stage_b = [&](int c, int sr, int slot) __attribute__((always_inline)) {   // rows sr * R .. of chunk c
@@ -175,6 +205,23 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
   unsigned pa[K];                                        // per-lane A read address for x shift d - LO, or out of range
 #pragma unroll
   for (int d = 0; d < K; ++d) pa[d] = ((unsigned)(rx + d - LO) < 8u) ? a_lane + (unsigned)((d - LO) * 64) : kOobN;
+  // X8: the FP8 fragments of tap pair pp = taps (2 pp, 2 pp + 1): K block khalf of the instruction is tap 2 pp + khalf, so a lane's
+  // 32 operand bytes are slots 2, 3 ([lo8 | hi8] / [W_hi8 | W_lo8]) of ITS tap's row; a tap beyond the row's last reads zeros
+  constexpr int NP = (K + 1) / 2;
+  unsigned pa8[NP], pb8[NP];
+  unsigned a8_d1 = 0u, b8_d1 = 0u;
+  if constexpr (X8) {
+    const int bkey = (l31 >> 2) & 3;
+    const unsigned a_row = lds0 + kAOffN + (unsigned)((pt * 8 + rx) * 64), b_row = lds0 + (unsigned)(l31 * 64);
+    a8_d1 = (unsigned)((((3 ^ pt) & 3) - ((2 ^ pt) & 3)) * 16);
+    b8_d1 = (unsigned)((((3 ^ bkey) & 3) - ((2 ^ bkey) & 3)) * 16);
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      const int d = 2 * pp + khalf;
+      pa8[pp] = (d < K && (unsigned)(rx + d - LO) < 8u) ? a_row + (unsigned)((d - LO) * 64 + (((2 ^ pt) & 3) << 4)) : kOobN;
+      pb8[pp] = (d < K) ? b_row + (unsigned)(d * kBTileN + (((2 ^ bkey) & 3) << 4)) : kOobN;
+    }
+  }
   auto mask_of = [&](int dzi, int dyi) __attribute__((always_inline)) -> unsigned {
     return (zmask_pack >> (4 * dzi)) & (ymask_pack >> (4 * dyi)) & 0xfu;
   };
@@ -263,6 +310,76 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
     }
   };
 
+
+  // ---- X8: f16 hi * W_hi per tap, FP8 cross terms per tap pair ---------------------------------------------------------------
+  uint4 a8[2][2], b8[2][2];                              // a8: TWO rolling tile buffers (tiles j and j + 2 of a cross step share one) x
+                                                         // [slot 2 (lo8), slot 3 (hi8)]; b8: [column tile][slot 2 (W_hi8), slot 3 (W_lo8)]
+  int sc_a = p.x8_scale_a, sc_b = p.x8_scale_b;          // E8M0 block scales (2^-sa, 2^-sb), one per operand and layer
+  asm volatile("" : "+v"(sc_a), "+v"(sc_b));             // the scale operands are VGPRs (hipcc fails to copy them out of SGPRs itself)
+  auto mma8 = [&](f32x16& c, const uint4 (&av)[2], const uint4 (&bv)[2]) __attribute__((always_inline)) {
+    const i32x8n_t a_ = {(int)av[0].x, (int)av[0].y, (int)av[0].z, (int)av[0].w, (int)av[1].x, (int)av[1].y, (int)av[1].z, (int)av[1].w};
+    const i32x8n_t b_ = {(int)bv[0].x, (int)bv[0].y, (int)bv[0].z, (int)bv[0].w, (int)bv[1].x, (int)bv[1].y, (int)bv[1].z, (int)bv[1].w};
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c, 0, 0, 0, sc_a, 0, sc_b);
+  };
+  // A cross step (the tap that ends a pair) walks the four tiles with two FP8 fragment buffers: tiles 0 / 1 arrive prefetched, tile
+  // j + 2's fragments of the SAME pair are read into tile j's buffer right behind tile j's MFMAs (tile j + 1's four MFMAs cover the
+  // LDS latency), and behind tiles 2 / 3 the buffers take tiles 0 / 1 of the NEXT pair, two taps ahead of their use
+  auto row8 = [&](unsigned mask_g, int base_g, int base_n, unsigned boff_g, unsigned boff_n, bool pair_end) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+      const bool last_u = (u == K - 1);
+      const bool cross = (u & 1) || last_u;              // this tap ends pair u >> 1: its FP8 MFMAs are issued here
+      const int cpp = u >> 1, npp = last_u ? 0 : (u >> 1) + 1;
+      const unsigned m_mm = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_g);   // a scalar: the tile skips are s_cbranch, not exec masks
+      const unsigned nb0 = pa[last_u ? 0 : u + 1] + (unsigned)(last_u ? base_n : base_g);
+      const unsigned bsrc = b_lane + (last_u ? boff_n : boff_g + (unsigned)((u + 1) * kBTileN));
+      const unsigned cb8 = pa8[cpp] + (unsigned)base_g;                               // this pair, tiles 2 / 3
+      const unsigned nb8 = pa8[npp] + (unsigned)(last_u ? base_n : base_g);           // next pair, tiles 0 / 1
+      const unsigned bsrc8 = pb8[npp] + (last_u ? boff_n : boff_g);
+      if (R > 1 && last_u && pair_end) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        wait_vm0();
+        __builtin_amdgcn_s_barrier();
+      }
+      if (u == 0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) b[0][n][0] = b[1][n][0];
+      }
+      uint4(&bc)[2][2] = b[u & 1];
+      uint4(&bn)[2][2] = b[(u + 1) & 1];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bn[n][0] = lds128n(bsrc + n * kTileN);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) {
+          mma<DT>(acc[j][0], a[j][0], bc[0][0]);
+          mma<DT>(acc[j][1], a[j][0], bc[1][0]);
+          if (cross) {
+            mma8(acc[j][0], a8[j & 1], b8[0]);
+            mma8(acc[j][1], a8[j & 1], b8[1]);
+          }
+        }
+        a[j][0] = lds128n(nb0 + j * kTileN);
+        if (cross) {
+          const unsigned src8 = j < 2 ? cb8 + (j + 2) * kTileN : nb8 + (j - 2) * kTileN;
+          a8[j & 1][0] = lds128n(src8);
+          a8[j & 1][1] = lds128n(src8 + a8_d1);
+        }
+      }
+      if (cross) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          b8[n][0] = lds128n(bsrc8 + n * kTileN);
+          b8[n][1] = lds128n(bsrc8 + b8_d1 + n * kTileN);
+        }
+      }
+    }
+    if (R == 1) {
+      wait_vm0();
+      __builtin_amdgcn_s_barrier();
+    }
+  };
+
   for (int c = 0; c < p.n_chunks; ++c) {
     __syncthreads();                       // every wave is done with the previous chunk
     stage_a(c);
@@ -274,6 +391,22 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
       const unsigned m0 = mask_of(0, 0);
       const unsigned nb0 = pa[0] + (unsigned)base_of(0, 0);
       const unsigned nb1 = nb0 + a_d1;
+      if constexpr (X8) {
+        const unsigned nb8 = pa8[0] + (unsigned)base_of(0, 0);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          b[1][n][0] = lds128n(b_lane + n * kTileN);
+          b8[n][0] = lds128n(pb8[0] + n * kTileN);
+          b8[n][1] = lds128n(pb8[0] + b8_d1 + n * kTileN);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j][0] = lds128n(nb0 + j * kTileN);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          a8[j][0] = lds128n(nb8 + j * kTileN);
+          a8[j][1] = lds128n(nb8 + a8_d1 + j * kTileN);
+        }
+      } else {
       load_b(b[1], b_lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -281,6 +414,7 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
           a[j][0] = lds128n(nb0 + j * kTileN);
           a[j][1] = lds128n(nb1 + j * kTileN);
         }
+      }
     }
     // row g = (dzi, dyi); its weights sit at LDS offset boff; the fill that keeps AHEAD slot fills in flight goes to `fslot`
     int dzi = 0, dyi = 0, fill = AHEAD, fslot = AHEAD % NS;
@@ -300,7 +434,8 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
       const unsigned mask_g = mask_of(dzi, dyi), mask_n = more ? mask_of(dzn, dyn) : 0u;
       const int base_g = base_of(dzi, dyi), base_n = more ? base_of(dzn, dyn) : 0;
       const bool pair_end = (g % R == R - 1) || !more;
-      row(mask_g, mask_n, base_g, base_n, boff, boff_n, pair_end);
+      if constexpr (X8) row8(mask_g, base_g, base_n, boff, boff_n, pair_end);
+      else row(mask_g, mask_n, base_g, base_n, boff, boff_n, pair_end);
       dzi = dzn; dyi = dyn; boff = boff_n;
     }
   }
@@ -374,10 +509,10 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
   epi_pass(std::integral_constant<int, 1>{});
 }
 
-template <int DT, int K, bool X3, bool WALK>
+template <int DT, int K, int MODE, bool WALK>
 __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
   if constexpr (!WALK) {
-    conv8n_tile<DT, K, X3>(p, blockIdx.x, threadIdx.x);
+    conv8n_tile<DT, K, MODE>(p, blockIdx.x, threadIdx.x);
   } else {
     // walking launch (kernels.h: ConvParams::walk), a kernel of its own so that the one-tile-per-workgroup kernel keeps its register
     // allocation: only the tiles below the live row count; the thread index is laundered per trip, otherwise hipcc hoists every
@@ -393,12 +528,12 @@ __global__ __launch_bounds__(kThreadsN) void conv8n_kernel(const ConvParams p) {
       if (bid != blockIdx.x) __syncthreads();    // the previous tile's epilogue is done with the LDS
       int tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
-      conv8n_tile<DT, K, X3>(p, bid, tid);
+      conv8n_tile<DT, K, MODE>(p, bid, tid);
     }
   }
 }
 
-template <int DT, int K, bool X3, bool WALK>
+template <int DT, int K, int MODE, bool WALK>
 int launch_conv8n_one_w(const ConvParams& p, hipStream_t stream) {
   constexpr int kMaxDevices = 64;
   static bool attr_set[kMaxDevices] = {};
@@ -407,33 +542,41 @@ int launch_conv8n_one_w(const ConvParams& p, hipStream_t stream) {
   constexpr int lds = lds_bytes_n<K>();
   static_assert(lds <= 163840 && 1024 * kEpiStrideN <= lds, "LDS budget");
   if (dev < 0 || dev >= kMaxDevices || !attr_set[dev]) {
-    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8n_kernel<DT, K, X3, WALK>),
+    NESTI_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8n_kernel<DT, K, MODE, WALK>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if (dev >= 0 && dev < kMaxDevices) attr_set[dev] = true;
   }
   const int groups = (p.m_tiles + 7) / 8;
   const unsigned n_blocks = (unsigned)(groups * 8 * 2 * p.n_tiles);
   dim3 grid(WALK ? std::min(n_blocks, kWalkGrid) : n_blocks), block(kThreadsN);
-  hipLaunchKernelGGL((conv8n_kernel<DT, K, X3, WALK>), grid, block, lds, stream, p);
+  hipLaunchKernelGGL((conv8n_kernel<DT, K, MODE, WALK>), grid, block, lds, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 // p.walk picks the walking instantiation (a separate kernel: kernels.h, ConvParams::walk)
-template <int DT, int K, bool X3>
+template <int DT, int K, int MODE>
 int launch_conv8n_one(const ConvParams& p, hipStream_t stream) {
-  return p.walk ? launch_conv8n_one_w<DT, K, X3, true>(p, stream) : launch_conv8n_one_w<DT, K, X3, false>(p, stream);
+  return p.walk ? launch_conv8n_one_w<DT, K, MODE, true>(p, stream) : launch_conv8n_one_w<DT, K, MODE, false>(p, stream);
 }
 
 template <int DT>
 int launch_conv8n_dt(const ConvParams& p, int k, hipStream_t stream) {
+  if constexpr (DT == NESTI_F16) {
+    if (p.x8) {
+      if (!p.aux8_in || p.aux8_stride <= 0 || !p.split) NESTI_FAIL("launch_conv8n: the FP8 cross-term loop needs the side buffer of e4m3 planes and pair outputs");
+      if (k == 5) return launch_conv8n_one<DT, 5, 2>(p, stream);
+      if (k == 3) return launch_conv8n_one<DT, 3, 2>(p, stream);
+    }
+  }
+  if (p.x8) NESTI_FAIL("launch_conv8n: the FP8 cross-term loop is an f16 pair-mode variant");
   if constexpr (DT != NESTI_F32) {
-    if (p.x3native && k == 5) return launch_conv8n_one<DT, 5, true>(p, stream);
-    if (p.x3native && k == 3) return launch_conv8n_one<DT, 3, true>(p, stream);
+    if (p.x3native && k == 5) return launch_conv8n_one<DT, 5, 1>(p, stream);
+    if (p.x3native && k == 3) return launch_conv8n_one<DT, 3, 1>(p, stream);
   }
   if (p.x3native) NESTI_FAIL("launch_conv8n: the pair K loop is for the 16-bit kernels");
-  if (k == 5) return launch_conv8n_one<DT, 5, false>(p, stream);
-  if (k == 3) return launch_conv8n_one<DT, 3, false>(p, stream);
+  if (k == 5) return launch_conv8n_one<DT, 5, 0>(p, stream);
+  if (k == 3) return launch_conv8n_one<DT, 3, 0>(p, stream);
   NESTI_FAIL("launch_conv8n: kernel size must be 3 or 5");
 }
 

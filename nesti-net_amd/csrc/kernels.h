@@ -72,6 +72,15 @@ struct ConvParams {
                        // are fill-bound, so the second product is nearly free, and it removes the weight-rounding half of the filter's error
   int x3native;        // pair modes: the kernels' pair K loop (conv.hip / conv8n.hip: X3) -- K chunks [hi | lo] x [W_hi | W_lo], three MFMAs
                        // per fragment set; the packed weights follow (model.hip: PackedLayer::x3n)
+  // FP8 cross terms (NESTI_F16X8 / NESTI_F16X8C; conv8n.hip X8).  Producer side (a 1x1x1 layer, conv.hip): aux8_out != NULL makes the
+  // FIRST tile group (conv1) also write the e4m3 planes of its activated outputs v = hi + lo into the side buffer -- per row and
+  // 64-channel group [lo8 64 B | hi8 64 B] with lo8 = e4m3(lo 2^x8_sa), hi8 = e4m3(v 2^x8_sc), saturated at +-448; aux8_stride = bytes
+  // per row.  Consumer side (conv8n_kernel): x8 = 1, aux8_in = that buffer, x8_scale_a / x8_scale_b = the E8M0 codes (127 - sa,
+  // 127 - sb) of the block scales that undo the pre-scales of the activation and weight planes
+  const void* aux8_in;
+  void* aux8_out;
+  int aux8_stride;
+  int x8, x8_sa, x8_sc, x8_scale_a, x8_scale_b;
   float acc_scale;     // the accumulators are multiplied by this before the bias (1, or 2^-s when the layer's packed weights
                        // carry a 2^s scale: NESTI_F16X3 keeps the weight pairs in f16's normal range that way)
   int8_t tap[kMaxTaps][4];   // dz, dy, dx, -

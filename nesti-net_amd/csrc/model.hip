@@ -133,7 +133,7 @@ struct LayerDesc {
   bool bn = true, relu = true;
 };
 
-struct BufSpec { int log2S; int C; bool f32; };
+struct BufSpec { int log2S; int C; bool f32; bool aux8 = false; };   // aux8: side buffer of e4m3 planes, 2 bytes per channel (conv8n.hip X8)
 
 struct Op {
   enum Kind { CONV, MAX, MAX3 } kind;   // MAX3: max_pool3d [3,3,3] stride 2 SAME, 3^3 (embedded) -> 2^3
@@ -144,6 +144,10 @@ struct Op {
   int layer = -1;
   int C = 0, k = 0, log2S = 0;
   bool out_f32 = false;
+  // FP8 cross terms (expert towers of NESTI_F16X8 / NESTI_F16X8C models): a block's conv1 (aux_out_buf >= 0) can also write the e4m3
+  // planes of its outputs; the block's tap layers (aux_in_buf >= 0, x8_bit = their bit of nesti_model::x8_mask) read them.
+  // x8_bits (producer) = the bits of the tap layers that read its planes; aux_layer (consumer) = the producer's layer index
+  int aux_out_buf = -1, aux_in_buf = -1, x8_bit = -1, x8_bits = 0, aux_layer = -1;
 };
 
 struct Tower {
@@ -159,6 +163,7 @@ struct Graph {
   nesti_config_t cfg;
   int gate_x0_log2S() const { return cfg.grid_n == 3 ? 2 : 3; }   // index space of the MuPS rows of one point
   int mups_cstride = 64;
+  bool x8 = false;           // NESTI_F16X8 / NESTI_F16X8C: the expert towers carry side buffers for the FP8 cross terms
   std::vector<LayerDesc> layers;
   Tower gate;
   std::vector<Tower> experts;
@@ -166,6 +171,8 @@ struct Graph {
 
 struct Builder {
   Graph& g;
+  bool x8 = false;           // expert towers of an NESTI_F16X8 / NESTI_F16X8C model: side buffers for the 8^3 blocks' tap layers
+  int x8_block = 0;          // ... and which 8^3 inception block of the tower is being built (0, 1)
   int s_real = 0;            // stamped on the layers built while it is set (conv_net_3g)
   explicit Builder(Graph& gg) : g(gg) {}
 
@@ -212,10 +219,22 @@ struct Builder {
     // its full-resolution columns are never written; with k0 == 1 (plain columns) the small standalone kernel pools them
     const bool fuse4 = then_maxpool && k0 > 1 && !s_real;
     if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 2; T.ops.back().mp_mode2 = fuse4 ? 1 : 0; }
+    const size_t conv1_op = T.ops.size() - 1;
+    int ab = -1;
+    if (x8 && log2S == 3 && !s_real && x8_block < 2 && (k0 == 3 || k0 == 5) && (k1 == 3 || k1 == 5)) {
+      BufSpec ax{log2S, Fp, false};
+      ax.aux8 = true;
+      T.bufs.push_back(ax);
+      ab = (int)T.bufs.size() - 1;
+      T.ops[conv1_op].aux_out_buf = ab;
+      T.ops[conv1_op].x8_bits = 3 << (2 * x8_block);
+    }
     conv(T, scope + "_conv2", k0, log2S, ob, 0, c1, H, ob, Fp);
     if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 1; }
+    if (ab >= 0) { T.ops.back().aux_in_buf = ab; T.ops.back().x8_bit = 2 * x8_block; T.ops.back().aux_layer = T.ops[conv1_op].layer; }
     conv(T, scope + "_conv3", k1, log2S, ob, 0, c1, H, ob, Fp + Hp);
     if (then_maxpool) { T.ops.back().mp_buf = pb; T.ops.back().mp_mode = 1; }
+    if (ab >= 0) { T.ops.back().aux_in_buf = ab; T.ops.back().x8_bit = 2 * x8_block + 1; T.ops.back().aux_layer = T.ops[conv1_op].layer; ++x8_block; }
     out_map->pos.clear();
     for (int i = 0; i < F; ++i) out_map->pos.push_back(i);
     for (int i = 0; i < H; ++i) out_map->pos.push_back(Fp + i);
@@ -367,8 +386,10 @@ struct Builder {
       return;
     }
     const int F1 = 128 / cnt;   // np.round(128 / divider) under Python-2 integer division  :254
+    x8 = g.x8; x8_block = 0;
     int b = inception(T, "inception1" + s, 0, m, F1, 3, 5, 3, &m);
     b = inception(T, "inception2" + s, b, m, 256, 3, 5, 3, &m, true);    // + maxpool3  :261
+    x8 = false;
     b = inception(T, "inception4" + s, b, m, 256, 2, 4, 2, &m, true);    // + maxpool5  :266
     b = inception(T, "inception6" + s, b, m, 512, 2, 4, 1, &m, true);    // + maxpool7  :271
     T.out_buf = fc_stack(T, b, m, {"fc1" + s, "fc2" + s, "fc3" + s, "fc4" + s}, {512, 128, 64, 3}, /*last_relu=*/false);
@@ -376,7 +397,7 @@ struct Builder {
   }
 };
 
-int build_graph(const nesti_config_t* cfg, Graph* g) {
+int build_graph(const nesti_config_t* cfg, Graph* g, bool x8 = false) {
   if (cfg->arch != NESTI_ARCH_EXPERTS && cfg->arch != NESTI_ARCH_SINGLE && cfg->arch != NESTI_ARCH_MULTI &&
       cfg->arch != NESTI_ARCH_SWITCH)
     NESTI_FAIL("unknown arch");
@@ -394,6 +415,7 @@ int build_graph(const nesti_config_t* cfg, Graph* g) {
       NESTI_FAIL("expert scale range outside [0, n_scales)");
   }
   g->cfg = *cfg;
+  g->x8 = x8 && cfg->arch == NESTI_ARCH_EXPERTS && cfg->grid_n == 8;
   g->mups_cstride = pad_to(20 * cfg->n_scales, kPad);
   g->layers.clear();
   Builder b(*g);
@@ -430,6 +452,9 @@ struct PackedLayer {
   bool x3n = false;          // pair modes: K chunks [hi | lo] / [W_hi | W_lo], three MFMAs per fragment set
   int mix_bit = -1;          // packed_mix entries: which bit of nesti_model::expert_mix switches this layer to the single-product loop
   float acc_scale = 1.0f;    // 2^-s when the packed weights carry a 2^s scale (NESTI_F16X3)
+  bool x8 = false;           // packed_x8 entries: rows [W_hi f16 16 ch | W_hi8 16 ch | W_lo8 16 ch] (conv8n.hip X8)
+  int x8_sb = 0;             // ... W_hi8 = e4m3(W_hi 2^sb), W_lo8 = e4m3(W_lo 2^(sb + 11))
+  int x8_sc = 0;             // producer layers (an 8^3 block's conv1): hi8 = e4m3(v 2^sc), lo8 = e4m3(lo 2^(sc + 11))
   int8_t tap[kMaxTaps][4];
 };
 
@@ -449,11 +474,15 @@ struct nesti_model {
   // and writes its outputs as pairs again
   std::vector<nesti::PackedLayer> packed_mix;
   int expert_mix = 0;
+  // NESTI_F16X8 / NESTI_F16X8C: the experts' tap layers at 8^3 once more in the FP8 cross-term packing; x8_mask picks which of them run
+  // it (include/nesti_hip.h: nesti_model_set_x8_layers)
+  std::vector<nesti::PackedLayer> packed_x8;
+  int x8_mask = 0;
   int gate_mix = 0;          // EXPERIMENT (nesti_model_set_gate_mix): the f16x3 gating passes run their tap layers single-product
   float tau = 0.25f;
   unsigned long long* cstat = nullptr;
   ~nesti_model() {
-    for (auto* v : {&packed, &packed_fast, &packed_mix})
+    for (auto* v : {&packed, &packed_fast, &packed_mix, &packed_x8})
       for (auto& p : *v) {
         if (p.wpk) (void)hipFree(p.wpk);
         if (p.bias) (void)hipFree(p.bias);
@@ -570,6 +599,121 @@ int x3_drop_mask(const LayerDesc& d) {
 #else
 inline int x3_drop_mask(const LayerDesc&) { return 0; }
 #endif
+
+// OCP e4m3 (1-4-3, bias 7, no infinities, largest finite 448) of a float, round to nearest even, saturating; subnormals kept
+uint8_t host_f32_to_e4m3(float f) {
+  const uint8_t sign = std::signbit(f) ? 0x80 : 0;
+  float a = fabsf(f);
+  if (!(a == a)) return 0x7f;
+  a = std::min(a, 448.f);
+  if (a == 0.f) return sign;
+  int e;
+  (void)frexpf(a, &e);                       // a = m 2^e, m in [0.5, 1)
+  e = std::max(e - 1, -6);                   // exponent of the leading bit, not below the smallest normal's
+  const float quantum = ldexpf(1.f, e - 3);
+  float q = nearbyintf(a / quantum);         // default rounding mode: to nearest, ties to even
+  float v = q * quantum;
+  if (v == 0.f) return sign;
+  if (v < ldexpf(1.f, -6)) return (uint8_t)(sign | (uint8_t)nearbyintf(v / ldexpf(1.f, -9)));   // subnormal: exponent field 0
+  int e2;
+  (void)frexpf(v, &e2);
+  e2 -= 1;
+  const int mant = (int)nearbyintf(v / ldexpf(1.f, e2 - 3)) - 8;
+  return (uint8_t)(sign | ((e2 + 7) << 3) | mant);
+}
+
+// The FP8 cross-term packing of one k^3 tap layer at 8^3 (conv8n.hip X8; NESTI_F16X8 / NESTI_F16X8C): per (column pair, 16-channel
+// chunk, tap) 64 rows x 64 B = [W_hi f16 k0..15 | W_hi8 k0..15 | W_lo8 k0..15] of the SAME scaled weights the pair packing holds
+// (W 2^e, |W| 2^e < 2^14): W_hi8 = e4m3(W_hi 2^sb), W_lo8 = e4m3((W - W_hi) 2^(sb + 11)) with sb = -6 (both below 256).
+int pack_layer_x8(const LayerDesc& d, const TensorTable& tt, PackedLayer* pl) {
+  if (!use_conv8(d) || !d.scope2.empty()) NESTI_FAIL("internal: pack_layer_x8 is for the k^3 tap layers at 8^3");
+  Folded f;
+  if (fold_layer(d, d.scope, tt, &f)) return 1;
+  const int lo = (d.k - 1) / 2;
+  pl->n_taps = 0;
+  std::vector<int> tap_widx;
+  for (int a = 0; a < d.k; ++a)
+    for (int bb = 0; bb < d.k; ++bb)
+      for (int c = 0; c < d.k; ++c) {
+        pl->tap[pl->n_taps][0] = (int8_t)(a - lo); pl->tap[pl->n_taps][1] = (int8_t)(bb - lo);
+        pl->tap[pl->n_taps][2] = (int8_t)(c - lo); pl->tap[pl->n_taps][3] = 0;
+        tap_widx.push_back((a * d.k + bb) * d.k + c);
+        ++pl->n_taps;
+      }
+  pl->kind = 2; pl->x3n = false; pl->x8 = true; pl->TN = 64;
+  if (d.Cout_p % 64 || d.Cin_p % kSplitGroup) NESTI_FAIL("internal: pack_layer_x8 needs 64-aligned channel counts");
+  pl->n_tiles = d.Cout_p / 64; pl->split_tile = pl->n_tiles;
+  constexpr int chunk_ch = 16;
+  pl->n_chunks = d.Cin_p / chunk_ch;
+  float wmax = 0.f;
+  for (size_t t = 0; t < tap_widx.size(); ++t) {
+    const float* wt = f.w + (size_t)tap_widx[t] * d.cin * d.cout;
+    for (int c = 0; c < d.cin; ++c)
+      for (int n = 0; n < d.cout; ++n) wmax = std::max(wmax, fabsf(wt[(size_t)c * d.cout + n] * f.scale[n]));
+  }
+  int e = 0;
+  if (wmax > 0.f && std::isfinite(wmax)) {
+    (void)frexpf(wmax, &e);
+    e = std::min(24, std::max(-8, 14 - e));      // as pack_layer: wmax 2^e in [2^13, 2^14)
+  }
+  const float wmul = ldexpf(1.0f, e);
+  pl->acc_scale = ldexpf(1.0f, -e);
+  pl->x8_sb = -6;
+  const float mul_hi8 = ldexpf(1.f, pl->x8_sb), mul_lo8 = ldexpf(1.f, pl->x8_sb + 11);
+  std::vector<int> inv(d.Cin_p, -1);
+  for (int c = 0; c < d.cin; ++c) inv[d.in_pos[c]] = c;
+  const size_t tile_bytes = (size_t)64 * 64;
+  const size_t total = (size_t)pl->n_tiles * pl->n_chunks * pl->n_taps * tile_bytes;
+  std::vector<unsigned char> host(total, 0);
+  for (int nt = 0; nt < pl->n_tiles; ++nt)
+    for (int ch = 0; ch < pl->n_chunks; ++ch)
+      for (int t = 0; t < pl->n_taps; ++t) {
+        unsigned char* tile = host.data() + (((size_t)nt * pl->n_chunks + ch) * pl->n_taps + t) * tile_bytes;
+        const float* wt = f.w + (size_t)tap_widx[t] * d.cin * d.cout;
+        for (int kc = 0; kc < chunk_ch; ++kc) {
+          const int cr = inv[ch * chunk_ch + kc];
+          if (cr < 0) continue;
+          const float* wrow = wt + (size_t)cr * d.cout;
+          for (int nl = 0; nl < 64; ++nl) {
+            const int n = nt * 64 + nl;
+            if (n >= d.cout) break;
+            const float v = wrow[n] * f.scale[n] * wmul;
+            const uint16_t h = host_f32_to_f16(v);
+            const float hf = host_f16_to_f32(h);
+            const int key = (nl >> 2) & 3;               // conv8n_kernel's weight-row swizzle
+            unsigned char* row = tile + (size_t)nl * 64;
+            memcpy(row + (((kc >> 3) ^ key) << 4) + (kc & 7) * 2, &h, 2);
+            row[((2 ^ key) << 4) + kc] = host_f32_to_e4m3(hf * mul_hi8);
+            row[((3 ^ key) << 4) + kc] = host_f32_to_e4m3((v - hf) * mul_lo8);
+          }
+        }
+      }
+  std::vector<float> bias_p((size_t)pl->n_tiles * 64, 0.f);
+  for (int n = 0; n < d.cout; ++n) bias_p[n] = f.bias[n];
+  NESTI_CHECK_HIP(hipMalloc(&pl->wpk, total));
+  NESTI_CHECK_HIP(hipMemcpy(pl->wpk, host.data(), total, hipMemcpyHostToDevice));
+  NESTI_CHECK_HIP(hipMalloc((void**)&pl->bias, bias_p.size() * sizeof(float)));
+  NESTI_CHECK_HIP(hipMemcpy(pl->bias, bias_p.data(), bias_p.size() * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// Power-of-two pre-scale of the e4m3 activation planes a block's conv1 writes for the FP8 cross terms: hi8 = e4m3(v 2^sc) must stay
+// below the format's 448.  A data-free bound from the layer's own batch-norm: after tf.nn.batch_normalization the pre-activation of
+// channel n is beta_n + gamma_n z with z ~ N(0, 1) on the data the statistics were taken from, so |v| <= |beta_n| + 8 |gamma_n| but for
+// 8-sigma events; 2^sc brings that bound into (128, 256].  A larger value saturates and loses only its own cross terms.
+int x8_activation_exponent(const LayerDesc& d, const TensorTable& tt) {
+  float amax = 16.f;
+  const nesti_tensor_t* beta = tt.get(d.scope + "/bn/beta");
+  const nesti_tensor_t* gamma = tt.get(d.scope + "/bn/gamma");
+  if (d.bn && beta && gamma && beta->data && gamma->data) {
+    amax = 0.f;
+    for (int n = 0; n < d.cout; ++n) amax = std::max(amax, fabsf(beta->data[n]) + 8.f * fabsf(gamma->data[n]));
+  }
+  if (!(amax > 0.f) || !std::isfinite(amax)) amax = 16.f;
+  int e;
+  (void)frexpf(amax, &e);                        // amax = m 2^e, m in [0.5, 1): amax <= 2^e
+  return std::min(20, std::max(-8, 8 - e));
+}
 
 int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer* pl) {
   const int n_parts = d.scope2.empty() ? 1 : 2;
@@ -696,7 +840,7 @@ int pack_layer(const LayerDesc& d, const TensorTable& tt, int dtype, PackedLayer
 // workspace planning and tower execution
 // ------------------------------------------------------------------------------------------
 size_t buf_bytes(const BufSpec& b, int NB, int dtype) {
-  const size_t e = b.f32 ? 4 : dtype_size(dtype) * act_planes(dtype);
+  const size_t e = b.aux8 ? 2 : b.f32 ? 4 : dtype_size(dtype) * act_planes(dtype);
   return align_up(((size_t)NB << (3 * b.log2S)) * b.C * e, 256);
 }
 // Workspace placement of a tower's buffers: a buffer lives from the first launch that writes it to the last launch that
@@ -711,9 +855,10 @@ Placement place_tower(const Tower& T, int NB, int dtype) {
   std::vector<int> first(n, 1 << 30), last(n, -1);
   for (int k = 0; k < n_ops; ++k) {
     const Op& op = T.ops[k];
-    for (int b : {op.out_buf, op.mp_buf})
+    for (int b : {op.out_buf, op.mp_buf, op.aux_out_buf})
       if (b >= 1) { first[b] = std::min(first[b], k); last[b] = std::max(last[b], k); }
-    if (op.in_buf >= 1) last[op.in_buf] = std::max(last[op.in_buf], k);
+    for (int b : {op.in_buf, op.aux_in_buf})
+      if (b >= 1) last[b] = std::max(last[b], k);
   }
   if (T.out_buf >= 1) last[T.out_buf] = n_ops;
   std::vector<int> order;
@@ -790,6 +935,8 @@ struct RunCtx {
   bool zero_lo = false;          // experiment (gate_mix == 2): every layer writes its outputs rounded to 16 bits (lo plane = 0)
   bool walk = false;             // this pass over a device-side list is probably empty (a later round, a widening pass): its conv
                                  // launches use small walking grids (kernels.h: ConvParams::walk)
+  int x8 = 0;                    // expert towers of an NESTI_F16X8 / NESTI_F16X8C model: nesti_model::x8_mask (which tap layers run the
+                                 // FP8 cross-term loop; their block's conv1 then also writes the e4m3 planes)
 };
 
 int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* ws, size_t ws_bytes, float** out) {
@@ -811,8 +958,10 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       // costs ~20 % more weight-tile fill and no matrix-pipe time that shows, and it removes the weight-rounding part of their error:
       // the filter's sigma on a logit difference drops from 0.021 to 0.012 (profiles/r05_gate_medium.txt), the threshold with it
       const bool x2l = rc.fast && rc.m->packed_fast[op.layer].wpk == nullptr;
+      const bool x8l = !rc.fast && !mixl && op.aux_in_buf >= 0 && op.x8_bit >= 0 && ((rc.x8 >> op.x8_bit) & 1) &&
+                       op.layer < (int)rc.m->packed_x8.size() && rc.m->packed_x8[op.layer].wpk;
       const PackedLayer& pl = x2l ? rc.m->packed[op.layer] : rc.fast ? rc.m->packed_fast[op.layer]
-                              : mixl ? rc.m->packed_mix[op.layer] : rc.m->packed[op.layer];
+                              : mixl ? rc.m->packed_mix[op.layer] : x8l ? rc.m->packed_x8[op.layer] : rc.m->packed[op.layer];
       ConvParams p;
       memset(&p, 0, sizeof(p));
       p.in_pair = mixl ? 1 : 0;
@@ -836,6 +985,15 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       p.m_tiles = pl.kind == 3 ? (rc.NB + 15) / 16 : pl.kind == 2 ? (rc.NB + 3) / 4 : (int)((rows + kTileM - 1) / kTileM);
       p.n_tiles = pl.n_tiles; p.split_tile = pl.split_tile; p.out_coff2 = op.out_coff2; p.pool_k = d.pool_k;
       if (op.mp_buf >= 0) { p.mp_out = ptr[op.mp_buf]; p.mp_cstride = T.bufs[op.mp_buf].C * planes; p.mp_mode = op.mp_mode; p.mp_mode2 = op.mp_mode2; }
+      if (x8l) {                                   // consumer: the FP8 cross-term loop on the planes the block's conv1 wrote
+        const int sc = rc.m->packed[op.aux_layer].x8_sc;
+        p.x8 = 1; p.aux8_in = ptr[op.aux_in_buf]; p.aux8_stride = T.bufs[op.aux_in_buf].C * 2;
+        p.x8_scale_a = 127 - (sc + 11); p.x8_scale_b = 127 - pl.x8_sb;
+      }
+      if (!rc.fast && op.aux_out_buf >= 0 && (rc.x8 & op.x8_bits) && !rc.m->packed_x8.empty()) {   // producer
+        p.aux8_out = ptr[op.aux_out_buf]; p.aux8_stride = T.bufs[op.aux_out_buf].C * 2;
+        p.x8_sc = rc.m->packed[op.layer].x8_sc; p.x8_sa = p.x8_sc + 11;
+      }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
       p.walk = rc.walk ? 1 : 0;
@@ -984,12 +1142,14 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
         const int32_t* list = lists + (size_t)e * B + (size_t)r * cap;
         const int32_t* cnt = ecounts + e * rounds + r;
         RunCtx rc{m, cap, cnt, list, stream, false, m->expert_mix};
+        rc.x8 = m->x8_mask;
         rc.walk = r >= 1;                      // an expert sees ~1 / E of a batch: rounds after the first are normally empty
         if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
         if (launch_scatter3(out, ostride, list, cnt, cap, normals, stream)) return 1;
       } else {        // reference behaviour: every expert on every point -> [E,B,3], rows [r * cap, ...) of the batch per round
         const int take = std::min(cap, B - r * cap);
         RunCtx rc{m, take, nullptr, nullptr, stream, false, m->expert_mix};
+        rc.x8 = m->x8_mask;
         if (run_tower(rc, T, (const unsigned char*)X0 + (size_t)r * cap * x0_row, tower_ws, tower_bytes_, &out)) return 1;
         if (launch_scatter3(out, ostride, nullptr, nullptr, take, normals + ((size_t)e * B + (size_t)r * cap) * 3, stream)) return 1;
       }
@@ -1093,15 +1253,18 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
                        nesti_model_t** out) {
   if (!cfg || !tensors || !out) NESTI_FAIL("nesti_model_create: null argument");
   if (dtype != NESTI_F32 && dtype != NESTI_BF16 && dtype != NESTI_F16 && dtype != NESTI_BF16X3 && dtype != NESTI_F16X3 &&
-      dtype != NESTI_F16X3C)
+      dtype != NESTI_F16X3C && dtype != NESTI_F16X8 && dtype != NESTI_F16X8C)
     NESTI_FAIL("nesti_model_create: bad dtype");
-  if (dtype == NESTI_F16X3C && cfg->arch != NESTI_ARCH_EXPERTS)
-    NESTI_FAIL("nesti_model_create: NESTI_F16X3C is the two-stage gate of experts_n_est; use NESTI_F16X3 for the other models");
+  if (dtype_cascade(dtype) && cfg->arch != NESTI_ARCH_EXPERTS)
+    NESTI_FAIL("nesti_model_create: NESTI_F16X3C / NESTI_F16X8C is the two-stage gate of experts_n_est; use NESTI_F16X3 for the other models");
+  if (dtype_x8(dtype) && (cfg->arch != NESTI_ARCH_EXPERTS || cfg->grid_n != 8))
+    NESTI_FAIL("nesti_model_create: NESTI_F16X8 / NESTI_F16X8C (FP8 cross terms in the expert towers) is for experts_n_est on the 8^3 grid");
   std::unique_ptr<nesti_model> m(new nesti_model());
-  m->cascade = dtype == NESTI_F16X3C;
+  m->cascade = dtype_cascade(dtype);
+  const bool x8 = dtype_x8(dtype);
   dtype = main_dtype(dtype);
   m->dtype = dtype;
-  if (build_graph(cfg, &m->graph)) return 1;
+  if (build_graph(cfg, &m->graph, x8)) return 1;
   TensorTable tt;
   for (int i = 0; i < n_tensors; ++i) if (tensors[i].name) tt.by_name[tensors[i].name] = &tensors[i];
   m->packed.resize(m->graph.layers.size());
@@ -1135,6 +1298,17 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
         if (pack_layer(d, tt, plain, &m->packed_mix[op.layer])) return 1;
         m->packed_mix[op.layer].mix_bit = 2 * idx + (d.scope.back() == '3' ? 1 : 0);
       }
+  }
+  if (x8) {
+    // the experts' tap layers at 8^3 once more in the FP8 cross-term packing, and the pre-scale of the planes their block's conv1 writes
+    m->packed_x8.resize(m->graph.layers.size());
+    for (const Tower& T : m->graph.experts)
+      for (const Op& op : T.ops) {
+        if (op.kind != Op::CONV) continue;
+        if (op.aux_out_buf >= 0) m->packed[op.layer].x8_sc = x8_activation_exponent(m->graph.layers[op.layer], tt);
+        if (op.aux_in_buf >= 0 && pack_layer_x8(m->graph.layers[op.layer], tt, &m->packed_x8[op.layer])) return 1;
+      }
+    m->x8_mask = 0xA;          // both 5^3 layers (include/nesti_hip.h: nesti_model_set_x8_layers)
   }
   if (m->cascade) {
     m->packed_fast.resize(m->graph.layers.size());
@@ -1172,6 +1346,14 @@ int nesti_model_set_expert_mix(nesti_model_t* m, int mask) {
   if (mask && m->packed_mix.empty()) NESTI_FAIL("nesti_model_set_expert_mix: pair-mode experts_n_est models (8^3 grid) created after nesti_experiment_mix_enable(1) only");
   if (mask < 0 || mask >= (1 << 6)) NESTI_FAIL("nesti_model_set_expert_mix: mask has six bits");
   m->expert_mix = mask;
+  return 0;
+}
+
+int nesti_model_set_x8_layers(nesti_model_t* m, int mask) {
+  if (!m) NESTI_FAIL("nesti_model_set_x8_layers: null model");
+  if (m->packed_x8.empty()) NESTI_FAIL("nesti_model_set_x8_layers: not an NESTI_F16X8 / NESTI_F16X8C model");
+  if (mask < 0 || mask > 0xF) NESTI_FAIL("nesti_model_set_x8_layers: mask has four bits (inception1 conv2 / conv3, inception2 conv2 / conv3)");
+  m->x8_mask = mask;
   return 0;
 }
 
@@ -1218,9 +1400,9 @@ int nesti_model_gate_error_import(nesti_model_t* m, const float* src_dev, int n,
 size_t nesti_tower_workspace_bytes(const nesti_config_t* cfg, int dtype, int tower, int batch) {
   if (!cfg || batch <= 0) return 0;
   Graph g;
-  if (build_graph(cfg, &g)) return 0;
+  if (build_graph(cfg, &g, dtype_x8(dtype))) return 0;
   if (tower < -1 || tower >= (int)g.experts.size()) return 0;
-  const int dt = tower < 0 && dtype == NESTI_F16X3C ? NESTI_F16 : main_dtype(dtype);
+  const int dt = tower < 0 && dtype_cascade(dtype) ? NESTI_F16 : main_dtype(dtype);
   return tower_bytes(tower < 0 ? g.gate : g.experts[tower], batch, dt);
 }
 

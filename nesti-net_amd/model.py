@@ -13,11 +13,12 @@ import numpy as np
 import torch
 
 from . import _lib
-from .config import ARCH_MULTI, ARCH_SINGLE, DTYPES, NestiConfig
+from .config import ARCH_MULTI, ARCH_SINGLE, CASCADE_DTYPES, DTYPES, NestiConfig
 
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16,
              "bf16x3": torch.bfloat16, "f16x3": torch.float16,   # pair modes: 16-bit elements, two planes [hi | lo] per 64-channel group
-             "f16x3c": torch.float16}                            # f16x3 with the two-stage gate (include/nesti_hip.h: NESTI_F16X3C)
+             "f16x3c": torch.float16,                            # f16x3 with the two-stage gate (include/nesti_hip.h: NESTI_F16X3C)
+             "f16x8": torch.float16, "f16x8c": torch.float16}    # f16x3 / f16x3c with the experts' 5^3 layers' cross terms through FP8 (NESTI_F16X8[C])
 
 
 def get_3d_grid_gmm(subdivisions=(8, 8, 8), variance=0.0156):
@@ -71,7 +72,8 @@ class NestiNet:
     MFMA products per multiply, a third of the 16-bit rate: f16x3 stays two orders of magnitude inside the reference's 1e-5
     cosine tolerance of the f32 mode, bf16x3 is at its edge).  'f16x3c' is f16x3 with the two-stage gate: the gating net
     runs in plain f16 first and only the queries whose f16 top-2 logit margin is below ``gate_margin`` are decided by the
-    f16x3 gating net (:meth:`set_gate_margin`, :meth:`cascade_stats`)."""
+    f16x3 gating net (:meth:`set_gate_margin`, :meth:`cascade_stats`).  'f16x8' / 'f16x8c' are f16x3 / f16x3c with the two cross
+    terms of the experts' 5^3 tap layers computed by one FP8 MFMA (include/nesti_hip.h: NESTI_F16X8; :meth:`set_x8_layers`)."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", max_batch=1024):
         self.lib = _lib.load()
@@ -93,7 +95,7 @@ class NestiNet:
             _lib.check(self.lib.nesti_model_create(ctypes.byref(self._c), arr, len(names), DTYPES[dtype],
                                                    ctypes.byref(self._handle)), "nesti_model_create")
         self._keep = None
-        self.cascade = dtype == "f16x3c"
+        self.cascade = dtype in CASCADE_DTYPES
         self.mups_cstride = self.lib.nesti_model_mups_cstride(self._handle)
         self._ws = None
         self._ws_batch = 0
@@ -127,6 +129,11 @@ class NestiNet:
         return {"queries": int(st.queries), "rechecked": int(st.rechecked), "changed": int(st.changed),
                 "max_margin_err": float(st.max_margin_err), "sigma": float(sigma), "tau": float(st.tau),
                 "widened": int(st.widened), "widen_events": int(st.widen_events), "tau_eff": float(st.tau_eff)}
+
+    def set_x8_layers(self, mask):
+        """dtype 'f16x8' / 'f16x8c': which expert tap layers at 8^3 take their cross terms through FP8 (``nesti_model_set_x8_layers``:
+        bit 0 / 1 = inception1 conv2 / conv3, bit 2 / 3 = inception2 conv2 / conv3; default 0b1010; 0 = f16x3 proper)."""
+        _lib.check(self.lib.nesti_model_set_x8_layers(self._handle, int(mask)), "nesti_model_set_x8_layers")
 
     def set_expert_mix(self, mask):
         """EXPERIMENT: which expert tap layers run a single 16-bit product (``nesti_model_set_expert_mix``; 0 = none)."""

@@ -25,13 +25,20 @@ class NormalEstimator:
         # order + ONE numpy RandomState stream over all patches in visiting order, utils/pcpnet_dataset.py:304-321), on the
         # host, ~0.5 ms per patch -- for diffing against a real reference run row by row (refsample.py).  The default 'hash'
         # is the GPU ball query with its order-independent uniform subset.
-        if subsample not in ("hash", "reference"):
-            raise ValueError("subsample must be 'hash' or 'reference'")
+        # Since round 6 'reference' runs on the GPU: ball sizes from a count pass, the random stream replayed natively on the host
+        # from those sizes (csrc/refreplay.cpp, a worker thread), the balls sorted into cKDTree's visiting order by the patch
+        # kernel (patches.hip: patches_ref_kernel) -- row for row what 'reference_host' (the scipy + numpy path) produces, at
+        # several times its speed.  A shape with a ball too large for the kernel's LDS sort falls back to the host path; both
+        # draw from ONE native stream object, so the stream position survives the switch.
+        if subsample not in ("hash", "reference", "reference_host"):
+            raise ValueError("subsample must be 'hash', 'reference' or 'reference_host'")
         self.subsample = subsample
         self._ref = None
-        if subsample == "reference":
-            from .refsample import ReferencePatchSampler
-            self._ref = ReferencePatchSampler(seed)
+        self._ref_failed = False
+        if subsample != "hash":
+            from .refsample import ReferencePatchSampler, RefStream
+            self._ref_stream = RefStream(seed)
+            self._ref = ReferencePatchSampler(seed, stream=self._ref_stream)
         self.use_graph = bool(use_graph)
         # n_streams > 1: consecutive batches alternate between HIP streams (own scratch arena each), so one batch's partially
         # filled last workgroup rounds overlap the other's kernels
@@ -97,6 +104,11 @@ class NormalEstimator:
         if first < 0 or count < 0 or first + count > cloud.patch_count:
             raise ValueError("patch rows [%d, %d) outside [0, %d)" % (first, first + count, cloud.patch_count))
         if self._ref is not None:
+            if self._ref_failed:
+                raise _lib.NestiError("a reference-order run failed half way: the shared random stream no longer lines up with "
+                                      "the reference's; create a new NormalEstimator")
+            if self.subsample == "reference" and count > 0:
+                return self._run_reference_gpu(cloud, first, count, normals, expert, probs, single_tower)
             return self._run_reference_order(cloud, first, count, normals, expert, probs, single_tower)
         if self._fused:
             main = torch.cuda.current_stream(self.device)
@@ -149,43 +161,124 @@ class NormalEstimator:
             return normals, None, None
         return normals, expert, probs
 
-    def _run_reference_order(self, cloud, first, count, normals, expert, probs, single_tower):
-        """Patch rows [first, first + count) with the reference's own subsample (host), then the usual forward pass.  The host
-        pass of batch k + 1 (scipy ball query + the replayed random stream, ``refsample.py``) runs in a worker thread while batch
-        k is uploaded and goes through the GPU; the sampler is only ever called from that one thread, batch after batch, so the
-        shared random stream stays in the reference's visiting order."""
+    def _prefetch(self, spans, make, consume):
+        """Producer / consumer over ``spans`` with two buffers in flight: ``make(i, span)`` runs in ONE worker thread, span after
+        span (the shared random stream stays in visiting order), ``consume(i, span, item)`` on the calling thread; the worker
+        may run one span ahead of the span being consumed.  Whatever fails, the worker is stopped and joined before the error
+        propagates, and the estimator refuses further reference-order runs (the stream position is lost)."""
         import queue
         import threading
-        if getattr(cloud, "_ref_tree", None) is None:
-            cloud._ref_tree = self._ref.build_tree(cloud.host_pts)
-        S, P = self.cfg.n_scales, self.cfg.num_point
-        pidx_host = cloud.pidx[first:first + count].cpu().numpy() if cloud.pidx is not None else None
-        spans = [(done, min(self.batch, count - done)) for done in range(0, count, self.batch)]
-        ready = queue.Queue()
-        free = threading.Semaphore(2)           # the sampler alternates between TWO buffers: a batch may only be produced once
-                                                # the batch before the previous one has been uploaded
+        ready, free, stop = queue.Queue(), threading.Semaphore(2), threading.Event()
 
         def produce():
             try:
-                for done, take in spans:
+                for i, span in enumerate(spans):
                     free.acquire()
-                    centers = pidx_host[done:done + take] if pidx_host is not None else np.arange(first + done, first + done + take)
-                    ready.put(self._ref.patches(cloud.host_pts, cloud._ref_tree, centers, cloud.r_abs, P))
+                    if stop.is_set():
+                        return
+                    ready.put(make(i, span))
             except BaseException as e:      # noqa: BLE001 -- hand the failure to the consumer instead of dying silently
                 ready.put(e)
 
         worker = threading.Thread(target=produce, daemon=True)
         worker.start()
-        for done, take in spans:
-            item = ready.get()
-            if isinstance(item, BaseException):
-                raise item
+        ok = False
+        try:
+            for i, span in enumerate(spans):
+                item = ready.get()
+                if isinstance(item, BaseException):
+                    raise item
+                consume(i, span, item, free.release)
+            ok = True
+        finally:
+            if not ok:
+                self._ref_failed = True
+                stop.set()
+                free.release()
+                free.release()
+            worker.join()
+
+    def _run_reference_order(self, cloud, first, count, normals, expert, probs, single_tower):
+        """Patch rows [first, first + count) with the reference's own subsample on the HOST (scipy ball query + the replayed random
+        stream, ``refsample.py``), then the usual forward pass.  The host pass of batch k + 1 runs in a worker thread while batch k is
+        uploaded and goes through the GPU."""
+        if getattr(cloud, "_ref_tree", None) is None:
+            cloud._ref_tree = self._ref.build_tree(cloud.host_pts)
+        S, P = self.cfg.n_scales, self.cfg.num_point
+        pidx_host = cloud.pidx[first:first + count].cpu().numpy() if cloud.pidx is not None else None
+        spans = [(done, min(self.batch, count - done)) for done in range(0, count, self.batch)]
+
+        def make(i, span):
+            done, take = span
+            centers = pidx_host[done:done + take] if pidx_host is not None else np.arange(first + done, first + done + take)
+            return self._ref.patches(cloud.host_pts, cloud._ref_tree, centers, cloud.r_abs, P)
+
+        def consume(i, span, item, release):
+            done, take = span
             p, n = item
             sl = slice(done, done + take)
             p_d, n_d = torch.from_numpy(p).to(self.device), torch.from_numpy(n).to(self.device).view(take, S)   # synchronous copies
-            free.release()                      # the host buffer may be refilled
+            release()                           # the host buffer may be refilled
             self.net.forward(p_d, n_d, out=(normals[sl], expert[sl], probs[sl]))
-        worker.join()
+
+        self._prefetch(spans, make, consume)
+        if single_tower:
+            return normals, None, None
+        return normals, expert, probs
+
+    def _run_reference_gpu(self, cloud, first, count, normals, expert, probs, single_tower):
+        """The same rows on the GPU.  cKDTree's result order is ascending position in ``tree.indices``, so
+        the reference's subsample needs (1) the ball sizes -- one count launch for the whole range, (2) its random stream replayed
+        over those sizes in visiting order -- natively, in a worker thread, one batch ahead (``refsample.RefStream``), (3) the
+        balls sorted by tree position with the picks applied -- ``patches_ref_kernel``, then the usual forward pass.  The patch
+        tensors equal the host path's bit for bit (tests/test_gpu_patches.py), hence so do the normals."""
+        S, P = self.cfg.n_scales, self.cfg.num_point
+        cloud.ensure_tree_order()
+        sizes = cloud.count_balls(first, count).cpu().numpy()                  # [count, S]; synchronises
+        cap = min(int(self.net.lib.nesti_patches_ref_max_ball()), 65535)
+        if int(sizes.max(initial=0)) > cap:
+            # a ball too large for the kernel's LDS sort (or the uint16 pick table): this shape goes through the host path, which
+            # draws from the same stream object
+            return self._run_reference_order(cloud, first, count, normals, expert, probs, single_tower)
+        spans = [(done, min(self.batch, count - done)) for done in range(0, count, self.batch)]
+        if getattr(self, "_ref_pinned", None) is None:
+            n = self.batch * S * P
+            self._ref_pinned = [(torch.empty(n, dtype=torch.int16).pin_memory(), torch.empty(self.batch * S, dtype=torch.int64).pin_memory())
+                                for _ in range(2)]
+            self._ref_dev = [(torch.empty(n, dtype=torch.int16, device=self.device),
+                              torch.empty(self.batch * S, dtype=torch.int64, device=self.device)) for _ in range(2)]
+            self._ref_copy = torch.cuda.Stream(device=self.device)
+
+        def make(i, span):
+            done, take = span
+            pk, off = self._ref_pinned[i & 1]
+            picks, _ = self._ref_stream.picks(sizes[done:done + take].ravel(), P, out=(pk.numpy().view(np.uint16), off.numpy()))
+            return len(picks)
+
+        main = torch.cuda.current_stream(self.device)
+        copied = [None, None]
+
+        def consume(i, span, n_picks, release):
+            done, take = span
+            pk, off = self._ref_pinned[i & 1]
+            pk_d, off_d = self._ref_dev[i & 1]
+            if copied[i & 1] is not None:
+                self._ref_copy.wait_event(copied[i & 1])       # the kernel that read this device slot two batches ago is done
+            with torch.cuda.stream(self._ref_copy):
+                pk_d[:n_picks].copy_(pk[:n_picks], non_blocking=True)
+                off_d[:take * S].copy_(off[:take * S], non_blocking=True)
+            self._ref_copy.synchronize()        # only the copies: the compute stream keeps running
+            release()                           # the pinned slot may be refilled
+            main.wait_stream(self._ref_copy)
+            sl = slice(done, done + take)
+            p, n = self._points[:take], self._n_eff[:take]
+            cloud.build_reference_order(first + done, take, pk_d, off_d, out=(p, n))
+            ev = torch.cuda.Event()
+            ev.record(main)
+            copied[i & 1] = ev
+            self.net.forward(p, n, out=(normals[sl], expert[sl], probs[sl]))
+
+        self._prefetch(spans, make, consume)
         if single_tower:
             return normals, None, None
         return normals, expert, probs

@@ -102,6 +102,66 @@ class CloudPatches:
             return points, n_eff, nbr, n_ball
         return points, n_eff
 
+    # ---- the reference's own subsample order on the GPU (utils/pcpnet_dataset.py:304, 320-321; patches.hip: patches_ref_kernel) ----
+    def ensure_tree_order(self):
+        """cKDTree's visiting order as a sort key: ``scipy.spatial.cKDTree(pts, 10)`` exactly as the reference builds it
+        (``utils/pcpnet_dataset.py:37``); ``query_ball_point`` returns a ball in ascending position in ``tree.indices``
+        (tests/test_refreplay.py), so the kernel only needs ``rank[i]`` = that position and ``order`` = ``tree.indices``."""
+        if getattr(self, "_tree_rank", None) is None:
+            from scipy import spatial
+            tree = spatial.cKDTree(self.host_pts, 10)
+            order = np.ascontiguousarray(tree.indices, dtype=np.int32)
+            rank = np.empty(self.n_points, np.int32)
+            rank[order] = np.arange(self.n_points, dtype=np.int32)
+            self._ref_tree = tree            # the host path (refsample.ReferencePatchSampler) uses the same tree
+            self._tree_order = torch.from_numpy(order).to(self.device)
+            self._tree_rank = torch.from_numpy(rank).to(self.device)
+        return self._tree_rank, self._tree_order
+
+    def count_balls(self, first, count, stream=None):
+        """Ball sizes [count, S] int32 (device) of patch rows [first, first + count): what the reference's random stream needs
+        (``nesti_patches_count``)."""
+        S = self.cfg.n_scales
+        if first < 0 or count < 0 or first + count > self.patch_count:
+            raise ValueError("patch rows [%d, %d) outside [0, %d)" % (first, first + count, self.patch_count))
+        qidx = self.pidx[first:first + count].contiguous() if self.pidx is not None else None
+        n_ball = torch.empty((count, S), dtype=torch.int32, device=self.device)
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_patches_count(ctypes.byref(self._c), _lib.ptr(self.cloud), self.n_points, _lib.ptr(qidx), count,
+                                                    self._r, ctypes.c_int(first), _lib.ptr(n_ball), _lib.ptr(self._ws), self._ws.numel(),
+                                                    ctypes.c_void_p(st.cuda_stream)), "nesti_patches_count")
+        return n_ball
+
+    def build_reference_order(self, first, count, picks, pick_offsets, want_idx=False, out=None, stream=None):
+        """Patch tensors of rows [first, first + count) exactly as the reference's ``PointcloudPatchDataset.__getitem__`` builds
+        them (``nesti_patches_query_ref``): balls in cKDTree's visiting order, over-full balls thinned by ``picks`` (uint16 device
+        tensor, any 2-byte dtype) at ``pick_offsets`` [count * S] int64 (device; -1 = the ball holds <= P points) -- the table
+        ``refsample.RefStream.picks`` replays from the ball sizes of :meth:`count_balls`."""
+        S, P = self.cfg.n_scales, self.cfg.num_point
+        if first < 0 or count < 0 or first + count > self.patch_count:
+            raise ValueError("patch rows [%d, %d) outside [0, %d)" % (first, first + count, self.patch_count))
+        rank, order = self.ensure_tree_order()
+        qidx = self.pidx[first:first + count].contiguous() if self.pidx is not None else None
+        if out is None:
+            points = torch.empty((count, S * P, 3), dtype=torch.float32, device=self.device)
+            n_eff = torch.empty((count, S), dtype=torch.int32, device=self.device)
+        else:
+            points, n_eff = out
+        nbr = torch.empty((count, S * P), dtype=torch.int32, device=self.device) if want_idx else None
+        if pick_offsets.dtype != torch.int64 or pick_offsets.numel() < count * S or picks.element_size() != 2:
+            raise ValueError("picks: 2-byte elements, pick_offsets: int64 [count * S]")
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_patches_query_ref(
+                ctypes.byref(self._c), _lib.ptr(self.cloud), self.n_points, _lib.ptr(qidx), count, self._r, ctypes.c_int(first),
+                _lib.ptr(rank), _lib.ptr(order), _lib.ptr(picks) if picks.numel() else None, _lib.ptr(pick_offsets), _lib.ptr(points),
+                _lib.ptr(n_eff), _lib.ptr(nbr), _lib.ptr(self._ws), self._ws.numel(), ctypes.c_void_p(st.cuda_stream)),
+                "nesti_patches_query_ref")
+        if want_idx:
+            return points, n_eff, nbr
+        return points, n_eff
+
 
 class PointcloudPatchDataset:
     """Shape list + per-shape patch counts, like the reference class of the same name

@@ -72,9 +72,13 @@ class ReferencePatchSampler:
     Patches must be requested in the reference's visiting order (shapes in list order, patch rows in order,
     ``SequentialPointcloudPatchSampler``) for the stream to line up with a reference run."""
 
-    def __init__(self, seed=REFERENCE_SEED):
+    def __init__(self, seed=REFERENCE_SEED, stream=None):
+        """``stream``: a :class:`RefStream` to draw the picks from instead of a numpy ``RandomState`` -- the same numbers
+        (tests/test_refreplay.py) without one Python call per over-full ball, and ONE stream object that the GPU reference-order
+        path (pipeline.py) can share, so that a shape may fall back to this host path without losing the stream position."""
         self.seed = int(seed)
-        self.rng = np.random.RandomState(self.seed)
+        self.stream = stream
+        self.rng = np.random.RandomState(self.seed) if stream is None else None
         self._bufs = {}            # (M, S, P) -> (points, idx): reused from batch to batch (first-touch page faults of a fresh
                                    # 180 MB tensor cost as much as the arithmetic that fills it)
 
@@ -112,16 +116,23 @@ class ReferencePatchSampler:
         sizes = np.stack([np.fromiter(map(len, balls[s]), dtype=np.int64, count=M) for s in range(S)], axis=1)
         n_eff[:] = np.minimum(sizes, P)                                     # :310-311
         # the random stream, in visiting order; only over-full balls draw from it (:320-321)
-        choice = self.rng.choice
         over = sizes > P
         picks = [None] * S
         pick_rows = [np.nonzero(over[:, s])[0] for s in range(S)]
-        for s in range(S):
-            picks[s] = np.empty((len(pick_rows[s]), P), np.int64)
-        fill = [0] * S
-        for i, s in zip(*np.nonzero(over)):                                 # row-major = patch-major, scale-minor
-            picks[s][fill[s]] = choice(int(sizes[i, s]), P, replace=False)
-            fill[s] += 1
+        if self.stream is not None:                                         # native replay: row-major = patch-major, scale-minor
+            flat_picks, offs = self.stream.picks(sizes.astype(np.int32).ravel(), P)
+            offs = offs.reshape(M, S)
+            table = flat_picks.reshape(-1, P)
+            for s in range(S):
+                picks[s] = table[offs[pick_rows[s], s] // P].astype(np.int64)
+        else:
+            choice = self.rng.choice
+            for s in range(S):
+                picks[s] = np.empty((len(pick_rows[s]), P), np.int64)
+            fill = [0] * S
+            for i, s in zip(*np.nonzero(over)):                             # row-major = patch-major, scale-minor
+                picks[s][fill[s]] = choice(int(sizes[i, s]), P, replace=False)
+                fill[s] += 1
         for s, rad in enumerate(r_abs):
             # all balls of the scale flattened in one pass (row order, traversal order within a row)
             flat = np.fromiter(itertools.chain.from_iterable(balls[s]), dtype=np.int64, count=int(sizes[:, s].sum()))

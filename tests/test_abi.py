@@ -151,7 +151,7 @@ def test_python_enums_follow_the_header():
         for name, val in re.findall(r"(NESTI_[A-Z0-9_]+)\s*=\s*(\d+)", body):
             enums[name] = int(val)
     want = {"f32": "NESTI_F32", "bf16": "NESTI_BF16", "f16": "NESTI_F16", "bf16x3": "NESTI_BF16X3", "f16x3": "NESTI_F16X3",
-            "f16x3c": "NESTI_F16X3C"}
+            "f16x3c": "NESTI_F16X3C", "f16x8": "NESTI_F16X8", "f16x8c": "NESTI_F16X8C"}
     assert set(config.DTYPES) == set(want)
     for k, name in want.items():
         assert config.DTYPES[k] == enums[name], k
@@ -176,5 +176,10 @@ def test_tower_workspace_bytes_from_the_configuration_alone():
         assert ws("f16", tower) > 0 and ws("f16x3", tower) == 2 * ws("f16", tower) and ws("bf16", tower) == ws("f16", tower)
         assert ws("f16", tower, 2048) == 2 * ws("f16", tower, 1024)
     assert ws("f16x3c", -1) == ws("f16", -1) and ws("f16x3c", 0) == ws("f16x3", 0)
+    # the FP8 cross-term modes add the side buffers of e4m3 planes to the expert towers (2 bytes per conv1 channel and voxel of the two
+    # 8^3 blocks; they share memory with later buffers where lifetimes allow), nothing to the gating net
+    assert ws("f16x8c", -1) == ws("f16", -1) and ws("f16x8", -1) == ws("f16x3", -1)
+    for tower in (0, 6):
+        assert ws("f16x3", tower) <= ws("f16x8", tower) <= ws("f16x3", tower) + 1024 * 512 * (128 + 256) * 2 and ws("f16x8c", tower) == ws("f16x8", tower)
     assert 1.5e6 < ws("f16", -1) / 1024 < 2.5e6                      # ~2 MB per query for the gating net in 16-bit
     assert ws("f16", 7) == 0 and ws("f16", -2) == 0 and ws("f16", 0, 0) == 0

@@ -1,0 +1,110 @@
+"""NESTI_F16X8 / NESTI_F16X8C (round 6): the expert towers' 5^3 tap layers with their two cross terms through ONE FP8 MFMA
+(conv8n.hip X8) -- pinned to f16x3 on 10k queries of the bench's cloud shape with a calibrated gate:
+  * arg-max IDENTICAL to f16x3's on every query (the gating net is untouched) and probabilities bit-identical,
+  * normals within 1 - cos <= 2.5e-6 of f16x3's on every query (the emulation that preceded the kernel predicts max ~1.1e-6 over
+    100k queries, profiles/r06_fp8_cross_step0.txt; the tolerance of the north star is 1e-5),
+  * every expert used, so all seven towers' X8 layers and their producers' e4m3 planes are exercised (Expert_6 has 42 -> 64 padded
+    input channels in inception1),
+  * layer mask 0 == f16x3 bit for bit, the 3^3 layers can be added (mask 0xF) within 1e-5,
+  * f16x8c == f16x8 in arg-max and normals once its gate margin is calibrated (the cascade is orthogonal to the expert arithmetic),
+and against the fp64 oracle on 256 queries (1 - cos <= 1e-5, arg-max exact outside the tie margin)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _omc(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return 1.0 - (a * b).sum(1) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-300)
+
+
+def test_x8_experts_pinned_to_f16x3(gpu_device):
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import parity, synth, weights
+    from nesti_net_amd.calibrate import calibrate_gate, calibrate_gate_margin
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from nesti_net_amd.provider import CloudPatches
+    cfg = NestiConfig()
+    N, Q = 100000, 10000
+    pts = synth.make_cloud("ellipsoid", n=N, seed=1234)[0]
+    q = np.arange(0, N, N // Q)[:Q]
+    cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
+    p_d, n_d = cp.build(0, Q)
+    W = calibrate_gate(cfg, weights.synthetic_weights(cfg), p_d[:512], n_d[:512], device=gpu_device)
+    n3, e3, p3 = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=Q)(p_d, n_d)
+    net8 = NestiNet(cfg, W, dtype="f16x8", device=gpu_device, max_batch=Q)
+    n8, e8, p8 = net8(p_d, n_d)
+    torch.cuda.synchronize()
+    n3, e3, n8, e8 = n3.cpu().numpy(), e3.cpu().numpy(), n8.cpu().numpy(), e8.cpu().numpy()
+    assert np.array_equal(e8, e3) and torch.equal(p8, p3)
+    assert len(np.unique(e3)) == cfg.n_experts
+    omc = _omc(n8, n3)
+    dn = np.linalg.norm(n8.astype(np.float64) - n3, axis=1)
+    print("f16x8 vs f16x3 on %d queries: 1-cos p50 %.3g p99 %.3g max %.3g, |dn| p50 %.3g max %.3g, routing %s"
+          % (Q, np.quantile(omc, .5), np.quantile(omc, .99), omc.max(), np.quantile(dn, .5), dn.max(), np.bincount(e3).tolist()))
+    assert omc.max() <= 2.5e-6
+    assert dn.max() > 0            # the FP8 loop really ran (mask 0 below is the bit-identical case)
+    # per expert: every tower within the bound (a wrong plane / scale in ONE tower must not hide behind the others)
+    for e in range(cfg.n_experts):
+        assert omc[e3 == e].max() <= 2.5e-6
+    # mask 0: f16x3 proper
+    net8.set_x8_layers(0)
+    n0, e0, _ = net8(p_d, n_d)
+    assert np.array_equal(n0.cpu().numpy(), n3) and np.array_equal(e0.cpu().numpy(), e3)
+    # all four tap layers at 8^3: within the north star's tolerance (the default keeps to the 5^3 layers: 2.5e-6 bar)
+    net8.set_x8_layers(0xF)
+    nf, _, _ = net8(p_d, n_d)
+    omc_f = _omc(nf.cpu().numpy(), n3)
+    print("mask 0xF (3^3 layers too): 1-cos p99 %.3g max %.3g" % (np.quantile(omc_f, .99), omc_f.max()))
+    assert omc_f.max() <= 1e-5
+    # one layer at a time: each bit alone moves the result, and stays inside the bound
+    for bit in range(4):
+        net8.set_x8_layers(1 << bit)
+        nb, _, _ = net8(p_d[:2000], n_d[:2000])
+        ob = _omc(nb.cpu().numpy(), n3[:2000])
+        assert 0 < ob.max() <= 2.5e-6, (bit, ob.max())
+    net8.set_x8_layers(0xA)
+    del net8
+    # the cascade on top: f16x8c == f16x8 once the margin is calibrated
+    net_c = NestiNet(cfg, W, dtype="f16x8c", device=gpu_device, max_batch=Q)
+    tau = calibrate_gate_margin(net_c, p_d[:2048], n_d[:2048])
+    nc, ec, _ = net_c(p_d, n_d)
+    st = net_c.cascade_stats()
+    print("f16x8c: tau %.4g" % tau, st)
+    assert 0 < st["rechecked"] < Q
+    assert np.array_equal(ec.cpu().numpy(), e8) and np.array_equal(nc.cpu().numpy(), n8)
+    with pytest.raises(Exception):
+        NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=8).set_x8_layers(0xA)
+
+
+def test_x8_against_the_oracle(gpu_device):
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import parity, synth, weights
+    from nesti_net_amd.calibrate import calibrate_gate
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from nesti_net_amd.provider import CloudPatches
+    from oracle import mups_ref, net_ref, patches_ref
+    cfg = NestiConfig()
+    pts = synth.make_cloud("torus", n=20000, seed=77, noise=0.006)[0]
+    q = np.arange(0, 20000, 78)[:256]
+    cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
+    p_d, n_d = cp.build(0, len(q))
+    W = calibrate_gate(cfg, weights.synthetic_weights(cfg), p_d, n_d, device=gpu_device)
+    o_pts, o_neff, _, _ = patches_ref.extract_patches(pts, q, cp.r_abs, cfg.num_point, cp.seed)
+    mups_o = mups_ref.mups_assemble(o_pts, o_neff, cfg.n_scales)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = [net_ref.moe_forward(mups_o[i:i + 64], W, expert_dict=cfg.expert_dict, dtype=torch.float64, top1_only=True) for i in range(0, len(q), 64)]
+    ref = {k: torch.cat([r[k] for r in ref]).numpy() for k in ("probs", "expert", "normals")}
+    n8, e8, _ = NestiNet(cfg, W, dtype="f16x8", device=gpu_device, max_batch=len(q))(p_d, n_d)
+    srt = np.sort(ref["probs"], axis=1)
+    agree = e8.cpu().numpy() == ref["expert"]
+    assert np.all(agree | (srt[:, -1] - srt[:, -2] < parity.TIE_MARGIN))
+    omc = _omc(n8.cpu().numpy()[agree], ref["normals"][agree])
+    print("f16x8 vs fp64 oracle: experts", np.unique(ref["expert"]).tolist(), "1-cos max %.3g" % omc.max())
+    assert omc.max() <= 1e-5
