@@ -9,10 +9,12 @@ rank processes --points queries per step whatever N is (weak scaling, real colle
 second leg times ONE cloud's rows sharded over the N ranks (the north star's "points of one cloud shard across the GPUs":
 strong scaling) and prints it as "strong" in the same line.
 
-The headline dtype is f16x3c: every output is computed in f16 hi + lo pairs (three MFMA products per multiply, f16x3) and
-the gating net additionally runs in plain f16 first as a filter (NESTI_F16X3C, include/nesti_hip.h) -- the mode that
-meets the north star's parity clause (see "parity": every arg-max difference and the 1 - cos distribution against the
-exact-fp32 mode over the whole timed cloud).  The plain 16-bit mode ("fast_mode", f16) is 1.7x faster and does NOT meet it.
+The headline dtype is f16x8c (round 6): every output is computed in f16 hi + lo pairs -- three MFMA products per multiply,
+f16x3 -- except that the experts' 5^3 tap layers compute their two CROSS terms (2^-11 of the result) with one FP8 MFMA
+(NESTI_F16X8C, include/nesti_hip.h), and the gating net additionally runs in plain f16 first as a filter (NESTI_F16X3C) --
+a mode that meets the north star's parity clause (see "parity": every arg-max difference and the 1 - cos distribution against
+the exact-fp32 mode over the whole timed cloud; "pair_cascade_mode" is last round's headline f16x3c on the same box, "x8_vs_f16x3"
+the FP8 layers' own footprint).  The plain 16-bit mode ("fast_mode", f16) is faster still and does NOT meet it.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -40,10 +42,13 @@ from nesti_net_amd import dist as ndist  # noqa: E402
 from nesti_net_amd.config import NestiConfig  # noqa: E402
 from nesti_net_amd.pipeline import NormalEstimator  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x3": 2500.0, "f16x3c": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x3": 2500.0, "f16x3c": 2500.0, "f16x8": 2500.0, "f16x8c": 2500.0, "f32": 157.3}   # dense, MI355X_MICROARCH.md
 # library batch caps by workspace (MB per query: f16 gate 2.0, f16x3 gate 3.9, f16x3 expert 2.6 -- nesti_tower_workspace_bytes)
-MAX_BATCH = {"bf16x3": 50000, "f16x3": 50000, "f32": 8192}
-PRODUCTS = {"bf16": 1, "f16": 1, "f32": 1, "bf16x3": 3, "f16x3": 3}   # MFMA products per multiply
+MAX_BATCH = {"bf16x3": 50000, "f16x3": 50000, "f16x8": 50000, "f32": 8192}
+PRODUCTS = {"bf16": 1, "f16": 1, "f32": 1, "bf16x3": 3, "f16x3": 3, "f16x8": 3}   # MFMA products per multiply
+CASCADE = ("f16x3c", "f16x8c")        # the two-stage gate
+X8 = ("f16x8", "f16x8c")              # FP8 cross terms in the experts' 5^3 tap layers: per row of 5 taps 5 f16 MFMAs + 3 FP8 MFMAs of K = 64,
+X8_K5_PRODUCTS = 11.0 / 5.0           # each counted as TWO f16 instructions (its pipe time at the nominal 2x rate): 2.2 f16-equivalents per multiply
 
 
 def make_clouds(n_clouds, n_points, stream=False):
@@ -193,7 +198,7 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=batch, use_graph=graph, n_streams=streams)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
     res = {}
-    if dtype == "f16x3c":
+    if dtype in CASCADE:
         # the gate margin: measured on a 1024-query sample of cloud 0 (every rank derives the same value), calibrate.py
         from nesti_net_amd.calibrate import GATE_MARGIN_SIGMAS, calibrate_gate_margin
         sp, sn = clouds[0].build(0, min(1024, clouds[0].patch_count))
@@ -221,7 +226,7 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     for _ in range(warmup):
         step()
     sync()
-    if dtype == "f16x3c":
+    if dtype in CASCADE:
         est.net.cascade_stats(reset=True)
     if timing:
         lib.nesti_profile_enable(1)
@@ -238,7 +243,7 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     if timing:
         res["prof_ms"], res["prof_n"] = _lib.profile_read(lib)
         lib.nesti_profile_enable(0)
-    if dtype == "f16x3c":
+    if dtype in CASCADE:
         res["cascade"] = est.net.cascade_stats()                      # rank 0's counters over the timed steps
     res.update({"elapsed": elapsed, "batch": est.batch, "streams": est.n_streams, "steps": steps,
                 "out": [t.cpu().numpy() for t in out]})
@@ -291,7 +296,7 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
     peak = PEAK_TFLOPS[dtype]
     cas = run.get("cascade")
     # (phase, MFMA products per multiply, queries that went through it)
-    if dtype == "f16x3c":
+    if dtype in CASCADE:
         phases = [("gate", 1, cas["queries"]), ("recheck", 3, cas["rechecked"]), ("experts", 3, rank0_pts)]
     else:
         phases = [("gate", PRODUCTS[dtype], rank0_pts), ("experts", PRODUCTS[dtype], rank0_pts)]
@@ -309,7 +314,8 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
         conv_n += n
         alg = 2.0 * (per_pt(k, 1, "gate") + per_pt(k, 1, "experts")) * rank0_pts
         # (f16x3c: the filter pass's one-tap layers multiply by the exact pair-packed weights -- two products per multiply)
-        issued = sum(2.0 * (2 if (dtype == "f16x3c" and ph == "gate" and name == "one_by_one_fc") else prod) *
+        issued = sum(2.0 * (2 if (dtype in CASCADE and ph == "gate" and name == "one_by_one_fc") else
+                            X8_K5_PRODUCTS if (dtype in X8 and ph == "experts" and name == "conv8_k5") else prod) *
                      per_pt(k, 2, "experts" if ph == "experts" else "gate") * q for ph, prod, q in phases)
         issued_sum += issued
         by_kernel[name] = {"ms_per_step": t_ms / steps, "launches_per_step": n / steps,
@@ -328,7 +334,7 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
     # scripts/summarize_pmc.py).  Counters cannot be read from inside the process, so the figure is quoted from
     # the profile only when dtype, batch and routing match; otherwise null.
     traffic, src = None, None
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         pmc_file = os.path.join(REPO, "profiles", name)
         if traffic is None and os.path.exists(pmc_file):
             pj = json.load(open(pmc_file))
@@ -338,7 +344,7 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
                 # the same counters per kernel class (plain + pair launches of the class), against THIS run's class times: the HBM-side
                 # rate each class sustains (rocprof bytes / hipEvent time; 8 TB/s peak) -- none of them is HBM-bound
                 for cname, ent in by_kernel.items():
-                    b = sum(pj["kernels"].get("conv:" + cname + sfx, {}).get("hbm_bytes_per_query", 0.0) for sfx in ("", "_pair"))
+                    b = sum(pj["kernels"].get("conv:" + cname + sfx, {}).get("hbm_bytes_per_query", 0.0) for sfx in ("", "_pair", "_x8"))
                     if b and ent["ms_per_step"]:
                         ent["hbm_MB_per_query_measured"] = b / 1e6
                         ent["hbm_GBps_measured"] = b * (rank0_pts / steps) / (ent["ms_per_step"] / 1e3) / 1e9
@@ -383,7 +389,7 @@ def strong_projection(args, cfg, W, cloud_np, dtype, dev, t_full_ms, ranks=8, st
         batch = max(256, min(batch, (((rows + streams - 1) // streams) + 255) // 256 * 256, (batch // streams + 255) // 256 * 256))
     est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=batch, use_graph=args.graph, n_streams=streams)
     cloud = est.prepare(cloud_np)
-    if dtype == "f16x3c":
+    if dtype in CASCADE:
         from nesti_net_amd.calibrate import calibrate_gate_margin
         sp, sn = cloud.build(0, min(1024, cloud.patch_count))
         calibrate_gate_margin(est.net, sp, sn)
@@ -434,8 +440,10 @@ def main():
     ap.add_argument("--batch", type=int, default=100000,
                     help="queries per library call, capped per dtype by the workspace (MAX_BATCH: 50 000 for f16x3c, a whole "
                          "100k-point cloud for f16 / bf16 at ~2 MB per query)")
-    ap.add_argument("--dtype", default="f16x3c", choices=["f16x3c", "f16x3", "bf16x3", "f16", "bf16", "f32"],
-                    help="f16x3c (default): f16 hi + lo pairs with the two-stage gate -- meets the north star's parity clause "
+    ap.add_argument("--dtype", default="f16x8c", choices=["f16x8c", "f16x8", "f16x3c", "f16x3", "bf16x3", "f16", "bf16", "f32"],
+                    help="f16x8c (default since round 6): f16x3c with the two cross terms of the experts' 5^3 tap layers through one FP8 "
+                         "MFMA (include/nesti_hip.h: NESTI_F16X8C; same arg-max as f16x3c, normals within ~1e-6 cosine of f16x3's); "
+                         "f16x3c: f16 hi + lo pairs with the two-stage gate -- meets the north star's parity clause "
                          "(bit-exact arg-max up to fp32 ties, 1e-5 cosine: see 'parity'); f16x3: the same without the gate filter; "
                          "f16 / bf16: plain 16-bit, faster, do NOT meet it (657 / 4 652 arg-max flips per 100k queries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -522,7 +530,7 @@ def main():
     legs = {}
     if headline and not args.no_secondary and world == 1:
         # the other modes on the same workload, a few steps each, each with its own parity object against the fp32 mode
-        for key, dt, st in (("fast_mode", "f16", 3), ("full_pair_mode", "f16x3", 1)) + ((("bf16_mode", "bf16", 3),) if args.bf16 else ()):
+        for key, dt, st in (("fast_mode", "f16", 3), ("full_pair_mode", "f16x3", 1), ("pair_cascade_mode", "f16x3c", 2)) + ((("bf16_mode", "bf16", 3),) if args.bf16 else ()):
             if dt != args.dtype:
                 legs[key] = (dt, st, timed_run(args, cfg, W, clouds_np, dt, st, 1, dev, world, rank, use_pg, timing,
                                                want_shard0=not args.no_parity, graph=False))
@@ -631,7 +639,7 @@ def main():
                 pk_s = roof_run["prof_ms"]["input"]["mups"] / roof_run["steps"] / 1e3
                 nq = float(len(clouds_np[0][0]))
                 rows_q = m["config"]["mean_patch_rows_per_query"]
-                out_b = 512 * 64 * (4 if args.dtype in ("f16x3c", "f16x3", "bf16x3", "f32") else 2)   # [512, 64] f32, or 16-bit pairs / plain
+                out_b = 512 * 64 * (4 if args.dtype in ("f16x8c", "f16x8", "f16x3c", "f16x3", "bf16x3", "f32") else 2)   # [512, 64] f32, or 16-bit pairs / plain
                 alg_b = out_b + 12.0 * rows_q + 12
                 res["mups"]["product_kernel"] = {
                     "kernel": "patches_mups_kernel", "ms_per_step": pk_s * 1e3, "queries_per_sec": nq / pk_s if pk_s else None,

@@ -33,22 +33,26 @@ def build_parser():
     p.add_argument("--batch_size", type=int, default=128, help="Batch size [default: 128]; the library batches internally")
     p.add_argument("--testset", type=str, default="testset_temp.txt", help="test set file name, default testset_temp.txt")
     # extensions (not in the reference)
-    p.add_argument("--dtype", default="auto", choices=["auto", "f16x3c", "f16x3", "bf16x3", "f16", "bf16", "f32"],
+    p.add_argument("--dtype", default="auto", choices=["auto", "f16x8c", "f16x8", "f16x3c", "f16x3", "bf16x3", "f16", "bf16", "f32"],
                    help="MFMA precision mode.  auto (default): the modes that keep .normals and .experts within the reference's "
-                        "tolerance (arg-max exact up to fp32 ties, 1e-5 cosine) -- f16x3c for experts_n_est (f16 hi + lo pairs "
-                        "behind the two-stage gate; its margin is calibrated on every shape and widens itself when the measured "
-                        "error approaches it), f16x3 for the other models.  NOTE: with f16x3c the .experts_probs rows of queries "
+                        "tolerance (arg-max exact up to fp32 ties, 1e-5 cosine) -- f16x8c for experts_n_est on the 8^3 grid (f16 hi + lo "
+                        "pairs behind the two-stage gate, whose margin is calibrated on every shape and widens itself when the measured "
+                        "error approaches it; the experts' 5^3 tap layers take their two cross terms through one FP8 MFMA: .experts "
+                        "equal f16x3c's, .normals stay within ~1e-6 cosine of f16x3's), f16x3c on the 3^3 grid, f16x3 for the other "
+                        "models.  NOTE: with f16x3c / f16x8c the .experts_probs rows of queries "
                         "the filter pass decided alone (~90 %%) are that pass's probabilities, within ~0.013 of the fp32 values; "
                         "use --dtype f16x3 when the probabilities themselves must hold 1e-4.  f16 / bf16: plain 16-bit, ~1.7x "
                         "faster, hundreds of arg-max flips per 100k points (DESIGN.md 2); f32: the exact-fp32 MFMA mode")
     p.add_argument("--lib_batch", type=int, default=0,
                    help="queries per library batch (0 = by dtype: 50000 for f16x3c / f16 / bf16, 25000 for the pair modes, 8192 "
                         "for f32; two such batches are in flight on two HIP streams)")
-    p.add_argument("--subsample", default="hash", choices=["hash", "reference"],
+    p.add_argument("--subsample", default="hash", choices=["hash", "reference", "reference_host"],
                    help="how balls with more than num_point points are thinned: hash = on the GPU, order-independent (default); "
-                        "reference = exactly like the reference (scipy cKDTree order + its RandomState stream, on the host, "
-                        "a fraction of a millisecond per patch: nesti-net_amd/refsample.py) for row-by-row diffs against a real "
-                        "reference run")
+                        "reference = exactly like the reference (cKDTree visiting order + its shared RandomState stream: "
+                        "utils/pcpnet_dataset.py:304, 320-321) for row-by-row diffs against a real reference run -- on the GPU since "
+                        "round 6 (ball sizes counted on the device, the stream replayed natively on the host from the sizes, the balls "
+                        "sorted into tree order in LDS); reference_host = the same rows by scipy + numpy on the host "
+                        "(nesti-net_amd/refsample.py), several times slower")
     p.add_argument("--synthetic_weights", action="store_true", help="use seeded synthetic weights if model.nstw is absent")
     return p
 
@@ -58,18 +62,18 @@ def fit_batch(cfg, dtype, batch, device, lanes=2, reserve=2 << 30):
     memory with ``reserve`` bytes to spare.  Sized from the configuration alone (nesti_tower_workspace_bytes: the gate
     tower dominates an arena; + the MuPS tensor and the per-query bookkeeping), before any model exists."""
     from . import _lib
-    from .config import DTYPES
+    from .config import CASCADE_DTYPES, DTYPES, PAIR_DTYPES
     lib = _lib.load()
     free = torch.cuda.mem_get_info(device)[0] - reserve
     c = cfg.to_c()
-    pair = dtype in ("f16x3", "bf16x3", "f16x3c")
+    pair = dtype in PAIR_DTYPES
     x0_per_q = 512 * 64 * (4 if (pair or dtype == "f32") else 2)          # MuPS rows of one query in the model's layout
     while batch > 256:
         ecap = batch if batch <= 8192 else (batch + 3) // 4 + 256      # csrc/model.hip: expert_cap / cascade_cap
         ccap = batch if batch <= 4096 else (batch + 3) // 4 + 256
         towers = [lib.nesti_tower_workspace_bytes(ctypes.byref(c), DTYPES[dtype], t, batch if t < 0 else ecap)
                   for t in range(-1, max(1, cfg.n_towers))]
-        if dtype == "f16x3c":                  # the recheck rounds run the f16x3 gate on a quarter of a large batch
+        if dtype in CASCADE_DTYPES:            # the recheck rounds run the f16x3 gate on a quarter of a large batch
             towers.append(lib.nesti_tower_workspace_bytes(ctypes.byref(c), DTYPES["f16x3"], -1, ccap))
         staging = 0 if cfg.n_gaussians == 8 else cfg.n_scales * cfg.num_point * 12     # 3^3 grid: the patch tensor is materialised
         arena = max(towers) + batch * (x0_per_q + staging + 160)
@@ -117,14 +121,18 @@ def main(argv=None):
     if cfg.arch != arch:
         raise SystemExit("--model %s does not match the trained model in %s" % (FLAGS.model, results_path))
     device = "cuda:%d" % FLAGS.gpu
-    dtype = FLAGS.dtype if FLAGS.dtype != "auto" else ("f16x3c" if arch == ARCH_EXPERTS else "f16x3")
-    if dtype == "f16x3c" and arch != ARCH_EXPERTS:
-        raise SystemExit("--dtype f16x3c is the two-stage gate of experts_n_est; use f16x3 for --model %s" % FLAGS.model)
+    from .config import CASCADE_DTYPES
+    dtype = FLAGS.dtype if FLAGS.dtype != "auto" else (("f16x8c" if cfg.n_gaussians == 8 else "f16x3c") if arch == ARCH_EXPERTS else "f16x3")
+    if dtype in CASCADE_DTYPES + ("f16x8",) and arch != ARCH_EXPERTS:
+        raise SystemExit("--dtype %s belongs to experts_n_est (two-stage gate / FP8 cross terms in the expert towers); use f16x3 for "
+                         "--model %s" % (dtype, FLAGS.model))
+    if dtype in ("f16x8", "f16x8c") and cfg.n_gaussians != 8:
+        raise SystemExit("--dtype %s needs the 8^3 Gaussian grid; use f16x3c" % dtype)
     dataset = PointcloudPatchDataset(pc_path, FLAGS.testset, cfg, seed=3627473, sparse_patches=FLAGS.sparse_patches,
                                      device=device)
     # two library batches in flight on two HIP streams; a batch is half the largest shape (rounded up to 256 rows) unless
     # that exceeds what the workspace of the dtype allows (~2 MB per query in f16x3c, twice that in the full pair modes)
-    lib_batch = FLAGS.lib_batch or {"f16x3c": 50000, "f16": 50000, "bf16": 50000, "f32": 8192}.get(dtype, 25000)
+    lib_batch = FLAGS.lib_batch or {"f16x3c": 50000, "f16x8c": 50000, "f16": 50000, "bf16": 50000, "f32": 8192}.get(dtype, 25000)
     half = (max(dataset.shape_patch_count + [1]) + 1) // 2
     batch = max(FLAGS.batch_size, min(lib_batch, max(1024, (half + 255) // 256 * 256)))
     # ... and what the device has free right now: two arenas (one per stream) + the 1024-query calibration workspace must fit
@@ -138,7 +146,7 @@ def main(argv=None):
 
     for ind, name in enumerate(dataset.shape_names):
         cloud = dataset.get_shape(ind)
-        if dtype == "f16x3c":
+        if dtype in CASCADE_DTYPES:
             # the gate margin, from up to 1024 queries of THIS shape (noise level and density change the activation and
             # error statistics from shape to shape); calibrate_gate_margin resets the gate's counters, so the statistics
             # printed below are this shape's
@@ -156,7 +164,7 @@ def main(argv=None):
         textio.write_i32(os.path.join(output_dir, name + ".experts"), expert.cpu().numpy())
         textio.write_f32(os.path.join(output_dir, name + ".experts_probs"), probs.cpu().numpy())
         printout("saved experts for " + name)
-        if dtype == "f16x3c":
+        if dtype in CASCADE_DTYPES:
             st = est.net.cascade_stats()
             printout("two-stage gate on %s: %d of %d queries decided by the f16x3 gate, f16 gate error on a logit difference "
                      "<= %.4g (tau %.4g, threshold now %.4g)" % (name, st["rechecked"], st["queries"], st["max_margin_err"],

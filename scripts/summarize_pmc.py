@@ -12,7 +12,7 @@ import sys
 root, queries, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 dtype = sys.argv[4] if len(sys.argv) > 4 else "f16"
 batch = int(sys.argv[5]) if len(sys.argv) > 5 else 25000
-DT = {"f32": "0", "bf16": "1", "f16": "2", "f16x3": "2", "f16x3c": "2", "bf16x3": "1"}[dtype]     # the kernels' element type
+DT = {"f32": "0", "bf16": "1", "f16": "2", "f16x3": "2", "f16x3c": "2", "f16x8": "2", "f16x8c": "2", "bf16x3": "1"}[dtype]     # the kernels' element type
 
 
 def family(k):
@@ -32,9 +32,9 @@ def family(k):
 
 def klass(k):
     """conv launches by kernel class and K loop: conv8 5^3 / 3^3, taps (igemm, several taps), 1x1 + FC (igemm, one tap)."""
-    m = re.search(r"conv8n_kernel<(\d), (\d), (true|false)", k)
+    m = re.search(r"conv8n_kernel<(\d), (\d), (\d|true|false)", k)        # third argument: 0 plain, 1 the pair K loop, 2 the FP8 cross-term loop
     if m:
-        return "conv8_k%s%s" % (m.group(2), "_pair" if m.group(3) == "true" else "")
+        return "conv8_k%s%s" % (m.group(2), {"true": "_pair", "1": "_pair", "2": "_x8"}.get(m.group(3), ""))
     m = re.search(r"conv4n_kernel<(\d), (\d), (true|false)", k)
     if m:
         return "taps_4_2" + ("_pair" if m.group(3) == "true" else "")

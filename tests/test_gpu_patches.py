@@ -107,3 +107,71 @@ def test_patches_tiny_and_degenerate_clouds(gpu_device):
         ref = patches_ref.extract_patches(pts, np.arange(len(pts)), r_abs, 8, cp.seed)
         assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
         assert np.array_equal(got[0].view(np.uint32), ref[0].view(np.uint32))
+
+
+@pytest.mark.parametrize("path", golden_patch_files(), ids=lambda p: p.split("patches_")[-1][:-4])
+def test_reference_order_rows_on_the_gpu_equal_the_reference_datasets(path, gpu_device):
+    """the reference's own subsample ORDER on the GPU -- ball sizes from the count kernel, the shared
+    RandomState replayed natively from those sizes (csrc/refreplay.cpp), the balls sorted into cKDTree's visiting order and the
+    picks applied by patches_ref_kernel.  The patch ROWS must equal what the reference's PointcloudPatchDataset itself produced
+    (tests/golden, queries visited in order with its seed), bit for bit, the capped balls INCLUDED."""
+    from nesti_net_amd.provider import CloudPatches
+    from nesti_net_amd.refsample import RefStream
+    g = load_golden_patches(path)
+    cfg = _cfg(g)
+    cp = CloudPatches(g["pts"], cfg, device=gpu_device, seed=g["seed"], pidx=g["queries"])
+    M, S, P = len(g["queries"]), len(g["radii"]), g["P"]
+    sizes = cp.count_balls(0, M).cpu().numpy()
+    assert np.array_equal(sizes, np.array([[len(b) for b in balls] for balls in g["balls"]]))
+    stream = RefStream(g["seed"])
+    # two batches: the stream carries over, the pick offsets are per call
+    cut = M // 3
+    got_p, got_n, got_i = [], [], []
+    for first, count in ((0, cut), (cut, M - cut)):
+        picks, offs = stream.picks(sizes[first:first + count].ravel(), P)
+        pk = torch.from_numpy(picks.view(np.int16).copy()).to(gpu_device)
+        of = torch.from_numpy(offs.copy()).to(gpu_device)
+        p, n, nbr = cp.build_reference_order(first, count, pk, of, want_idx=True)
+        got_p.append(p.cpu().numpy()); got_n.append(n.cpu().numpy()); got_i.append(nbr.cpu().numpy())
+    points, n_eff, nbr = np.concatenate(got_p), np.concatenate(got_n), np.concatenate(got_i)
+    assert np.array_equal(n_eff, g["n_eff"])
+    capped = int((sizes > P).sum())
+    assert np.array_equal(points.view(np.uint32), g["points"].view(np.uint32)), "%d capped balls" % capped
+    if "100k" in path or "gradient" in path:
+        assert capped > 0
+    for q in range(M):                       # the neighbour indices are members of the ball, without repetition
+        for s in range(S):
+            sel = nbr[q, s * P:s * P + n_eff[q, s]]
+            assert len(np.unique(sel)) == len(sel) and np.isin(sel, g["balls"][q][s]).all()
+            assert np.all(nbr[q, s * P + n_eff[q, s]:(s + 1) * P] == -1)
+
+
+def test_reference_order_gpu_equals_the_host_sampler_on_a_dense_cloud(gpu_device):
+    """3 000 queries of a 100k-point cloud with a density gradient (the largest scale over-full on most queries, the middle one on
+    the dense side): the GPU reference-order rows equal refsample.ReferencePatchSampler's (scipy + numpy on the host) bit for bit, and
+    the estimator's two reference modes write the same normals."""
+    from nesti_net_amd import synth, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.pipeline import NormalEstimator
+    from nesti_net_amd.provider import CloudPatches
+    from nesti_net_amd.refsample import ReferencePatchSampler, RefStream
+    cfg = NestiConfig()
+    pts = synth.make_cloud("ellipsoid", n=100000, seed=99, density="gradient")[0]
+    q = np.arange(0, 100000, 33)[:3000]
+    cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
+    sizes = cp.count_balls(0, len(q)).cpu().numpy()
+    over = (sizes > cfg.num_point).mean(0)
+    print("ball sizes: max", sizes.max(0), "mean", sizes.mean(0).round(1), "over-full fraction per scale", over.round(3))
+    assert over[2] > 0.5 and (sizes <= cfg.num_point).any()      # both branches of utils/pcpnet_dataset.py:310-321 are exercised
+    stream = RefStream(3627473)
+    picks, offs = stream.picks(sizes.ravel(), cfg.num_point)
+    p, n = cp.build_reference_order(0, len(q), torch.from_numpy(picks.view(np.int16).copy()).to(gpu_device), torch.from_numpy(offs.copy()).to(gpu_device))
+    host = ReferencePatchSampler(3627473)
+    hp, hn = host.patches(pts, host.build_tree(pts), q.astype(np.int64), cp.r_abs, cfg.num_point)
+    assert np.array_equal(n.cpu().numpy(), hn)
+    assert np.array_equal(p.cpu().numpy().view(np.uint32), hp.view(np.uint32))
+    W = weights.synthetic_weights(cfg)
+    a = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=1024, subsample="reference").estimate(pts, pidx=q)
+    b = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=700, subsample="reference_host").estimate(pts, pidx=q)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)

@@ -385,9 +385,11 @@ def test_run_many_equals_per_shape_runs(gpu_device):
             assert torch.equal(x, y)
 
 
-def test_reference_order_subsample_feeds_the_same_forward(gpu_device):
-    """NormalEstimator(subsample='reference'): the reference's own thinning of balls larger than P (host: scipy cKDTree +
-    one RandomState stream in visiting order, utils/pcpnet_dataset.py:304-321) in front of the usual forward pass.  On the
+@pytest.mark.parametrize("mode", ["reference", "reference_host"])
+def test_reference_order_subsample_feeds_the_same_forward(gpu_device, mode):
+    """NormalEstimator(subsample='reference' / 'reference_host'): the reference's own thinning of balls larger than P (cKDTree
+    visiting order + one RandomState stream in visiting order, utils/pcpnet_dataset.py:304-321; 'reference' = on the GPU from the
+    natively replayed stream, 'reference_host' = scipy + numpy on the host) in front of the usual forward pass.  On the
     100k golden fixture -- 32 queries, the largest scale capped on every one -- the outputs equal a forward pass over
     the patch tensors the reference dataset itself produced, bit for bit, and a second cloud continues the stream."""
     from conftest import golden_patch_files, load_golden_patches
@@ -400,7 +402,7 @@ def test_reference_order_subsample_feeds_the_same_forward(gpu_device):
     W = weights.synthetic_weights(cfg)
     net = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=len(g["queries"]))
     want = [t.cpu().numpy() for t in net(torch.as_tensor(g["points"], device=gpu_device), torch.as_tensor(g["n_eff"], device=gpu_device))]
-    est = NormalEstimator(cfg, W, dtype="f16x3", device=gpu_device, batch=10, seed=g["seed"], subsample="reference")
+    est = NormalEstimator(cfg, W, dtype="f16x3", device=gpu_device, batch=10, seed=g["seed"], subsample=mode)
     got = est.estimate(g["pts"], pidx=g["queries"])
     assert (g["n_eff"] == cfg.num_point).any()
     for a, b in zip(got, want):
