@@ -180,7 +180,7 @@ def mups_leg(points, steps, warmup, cfg, dev):
 
 
 def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, use_pg, timing, want_shard0=True, strong=False,
-              streams=1, graph=None):
+              streams=1, graph=None, x8_layers=None):
     """W warm-up steps, then exactly ``steps`` timed steps between barrier + synchronize pairs; max over ranks.
     ``strong``: a step is ONE cloud (clouds_np[0]) whose rows are sharded over the ranks (dist.estimate_sharded).
     Returns the elapsed seconds, the kernel-time table (rank 0), the last cloud's gathered results, this rank's
@@ -196,6 +196,8 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     if streams > 1:          # `streams` library batches in flight, together no more rows than one single-stream batch would hold
         batch = max(256, min(batch, (((rank_rows + streams - 1) // streams) + 255) // 256 * 256, (batch // streams + 255) // 256 * 256))
     est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=batch, use_graph=graph, n_streams=streams)
+    if x8_layers is not None:          # which expert tap layers take their cross terms through FP8 (include/nesti_hip.h: nesti_model_set_x8_layers)
+        est.net.set_x8_layers(x8_layers)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
     res = {}
     if dtype in CASCADE:
@@ -534,6 +536,11 @@ def main():
             if dt != args.dtype:
                 legs[key] = (dt, st, timed_run(args, cfg, W, clouds_np, dt, st, 1, dev, world, rank, use_pg, timing,
                                                want_shard0=not args.no_parity, graph=False))
+        if args.dtype == "f16x8c":
+            # NOT the default: the 3^3 tap layers at 8^3 through FP8 as well (mask 0xF).  Faster, and inside the 1e-5 tolerance, but
+            # the emulation's worst query of this cloud sits at 3.5e-6, above the 2.5e-6 bar the default (5^3 only) is held to
+            legs["x8_all_8cubed_taps_mode"] = ("f16x8c", 2, timed_run(args, cfg, W, clouds_np, "f16x8c", 2, 1, dev, world, rank, use_pg, timing,
+                                                                      want_shard0=not args.no_parity, graph=False, x8_layers=0xF))
 
     if rank == 0:
         elapsed = main_run["elapsed"]

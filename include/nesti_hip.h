@@ -306,6 +306,9 @@ int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t
  * `batch` queries at a time.  The patch tensors only ever live in ws_dev
  * (nesti_estimate_workspace_bytes(m, batch) bytes).  Outputs as nesti_forward: [M,3], [M], [M,E]. */
 size_t nesti_estimate_workspace_bytes(const nesti_model_t* m, int batch);
+/* The same figure from the configuration alone (no model, no device): what a caller needs to size batches against free memory
+ * before anything is created (nesti-net_amd/cli.py: fit_batch).  dtype as nesti_model_create. */
+size_t nesti_estimate_workspace_bytes_for_config(const nesti_config_t* cfg, int dtype, int batch);
 int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N,
                            const int32_t* query_idx_dev, int M, const double* r_abs, uint64_t seed,
                            int query_row0, int batch, int build_grid, void* grid_ws_dev,

@@ -82,6 +82,7 @@ SIGNATURES = {
     "nesti_experts_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "nesti_forward": (_i, [_vp, _vp, _vp, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "nesti_estimate_workspace_bytes": (_sz, [_vp, _i]),
+    "nesti_estimate_workspace_bytes_for_config": (_sz, [_cfgp, _i, _i]),
     "nesti_estimate_normals": (_i, [_vp, _vp, _i, _vp, _i, ctypes.POINTER(ctypes.c_double), _u64, _i, _i, _i, _vp, _sz,
                                     _vp, _sz, _vp, _vp, _vp, _vp]),
     "nesti_crc32c": (ctypes.c_uint32, [_vp, _sz, ctypes.c_uint32]),

@@ -59,25 +59,17 @@ def build_parser():
 
 def fit_batch(cfg, dtype, batch, device, lanes=2, reserve=2 << 30):
     """The largest batch <= ``batch`` (halving, 256-row granularity, >= 256) whose ``lanes`` arenas fit the device's free
-    memory with ``reserve`` bytes to spare.  Sized from the configuration alone (nesti_tower_workspace_bytes: the gate
-    tower dominates an arena; + the MuPS tensor and the per-query bookkeeping), before any model exists."""
+    memory with ``reserve`` bytes to spare.  The arena size comes from the library's own layout, from the configuration alone
+    (``nesti_estimate_workspace_bytes_for_config`` == ``nesti_estimate_workspace_bytes`` of the model that will be created:
+    tests/test_abi.py), before any model exists."""
     from . import _lib
-    from .config import CASCADE_DTYPES, DTYPES, PAIR_DTYPES
+    from .config import DTYPES
     lib = _lib.load()
     free = torch.cuda.mem_get_info(device)[0] - reserve
     c = cfg.to_c()
-    pair = dtype in PAIR_DTYPES
-    x0_per_q = 512 * 64 * (4 if (pair or dtype == "f32") else 2)          # MuPS rows of one query in the model's layout
     while batch > 256:
-        ecap = batch if batch <= 8192 else (batch + 3) // 4 + 256      # csrc/model.hip: expert_cap / cascade_cap
-        ccap = batch if batch <= 4096 else (batch + 3) // 4 + 256
-        towers = [lib.nesti_tower_workspace_bytes(ctypes.byref(c), DTYPES[dtype], t, batch if t < 0 else ecap)
-                  for t in range(-1, max(1, cfg.n_towers))]
-        if dtype in CASCADE_DTYPES:            # the recheck rounds run the f16x3 gate on a quarter of a large batch
-            towers.append(lib.nesti_tower_workspace_bytes(ctypes.byref(c), DTYPES["f16x3"], -1, ccap))
-        staging = 0 if cfg.n_gaussians == 8 else cfg.n_scales * cfg.num_point * 12     # 3^3 grid: the patch tensor is materialised
-        arena = max(towers) + batch * (x0_per_q + staging + 160)
-        if lanes * arena <= free:
+        arena = lib.nesti_estimate_workspace_bytes_for_config(ctypes.byref(c), DTYPES[dtype], batch)
+        if arena and lanes * arena <= free:
             break
         batch = max(256, (batch // 2 + 255) // 256 * 256)
     return batch

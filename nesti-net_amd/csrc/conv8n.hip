@@ -205,22 +205,17 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
   unsigned pa[K];                                        // per-lane A read address for x shift d - LO, or out of range
 #pragma unroll
   for (int d = 0; d < K; ++d) pa[d] = ((unsigned)(rx + d - LO) < 8u) ? a_lane + (unsigned)((d - LO) * 64) : kOobN;
-  // X8: the FP8 fragments of tap pair pp = taps (2 pp, 2 pp + 1): K block khalf of the instruction is tap 2 pp + khalf, so a lane's
-  // 32 operand bytes are slots 2, 3 ([lo8 | hi8] / [W_hi8 | W_lo8]) of ITS tap's row; a tap beyond the row's last reads zeros
-  constexpr int NP = (K + 1) / 2;
-  unsigned pa8[NP], pb8[NP];
-  unsigned a8_d1 = 0u, b8_d1 = 0u;
+  // X8: one FP8 instruction takes a PAIR of taps -- K block khalf (lanes 0-31 / 32-63) is the pair's tap khalf, and a lane's 32
+  // operand bytes are slots 2, 3 ([lo8 | hi8] / [W_hi8 | W_lo8]) of ITS tap's row.  The taps of a chunk are paired as one flat
+  // sequence (K is odd: rows alternate between (0 1)(2 3)(4 | next row's 0) and (1 2)(3 4)), so a chunk issues K^3 / 2 FP8
+  // instructions per tile, not K^2 (K + 1) / 2; the pair that straddles two rows takes each half's liveness from its own row.
+  unsigned dslot_a = 0u, a8_d1 = 0u, b8k = 0u, b8_d1 = 0u;
   if constexpr (X8) {
     const int bkey = (l31 >> 2) & 3;
-    const unsigned a_row = lds0 + kAOffN + (unsigned)((pt * 8 + rx) * 64), b_row = lds0 + (unsigned)(l31 * 64);
+    dslot_a = (unsigned)((((2 ^ pt) & 3) - a_sw) * 16);          // from a tap's f16 fragment address (slot khalf) to its slot 2
     a8_d1 = (unsigned)((((3 ^ pt) & 3) - ((2 ^ pt) & 3)) * 16);
+    b8k = lds0 + (unsigned)(l31 * 64 + (((2 ^ bkey) & 3) << 4) + khalf * kBTileN);   // slot 2 of this column's row in tap khalf of a weight row
     b8_d1 = (unsigned)((((3 ^ bkey) & 3) - ((2 ^ bkey) & 3)) * 16);
-#pragma unroll
-    for (int pp = 0; pp < NP; ++pp) {
-      const int d = 2 * pp + khalf;
-      pa8[pp] = (d < K && (unsigned)(rx + d - LO) < 8u) ? a_row + (unsigned)((d - LO) * 64 + (((2 ^ pt) & 3) << 4)) : kOobN;
-      pb8[pp] = (d < K) ? b_row + (unsigned)(d * kBTileN + (((2 ^ bkey) & 3) << 4)) : kOobN;
-    }
   }
   auto mask_of = [&](int dzi, int dyi) __attribute__((always_inline)) -> unsigned {
     return (zmask_pack >> (4 * dzi)) & (ymask_pack >> (4 * dyi)) & 0xfu;
@@ -323,45 +318,74 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
   };
   // A cross step (the tap that ends a pair) walks the four tiles with two FP8 fragment buffers: tiles 0 / 1 arrive prefetched, tile
   // j + 2's fragments of the SAME pair are read into tile j's buffer right behind tile j's MFMAs (tile j + 1's four MFMAs cover the
-  // LDS latency), and behind tiles 2 / 3 the buffers take tiles 0 / 1 of the NEXT pair, two taps ahead of their use
-  auto row8 = [&](unsigned mask_g, int base_g, int base_n, unsigned boff_g, unsigned boff_n, bool pair_end) __attribute__((always_inline)) {
+  // LDS latency), and behind tiles 2 / 3 the buffers take tiles 0 / 1 of the NEXT pair.
+  // Row type T = row parity within the chunk.  T = 0: pairs (0 1) (2 3) ... end at the odd taps, and the last tap pairs with tap 0
+  // of the NEXT row (K block 1 reads that row's source run and weights; a tile dead in one of the two rows reads zeros for that
+  // half, and the instruction is issued when it is live in either).  T = 1: tap 0 is already done, pairs (1 2) (3 4) ... end at the
+  // even taps.  The last row of a chunk is of type 0 (K^2 is odd) and has no next row: mask_n = 0 makes its second half zeros.
+  auto a8_same = [&](int d0, unsigned base) __attribute__((always_inline)) -> unsigned {     // pair (d0 | d0 + 1) of one row
+    return (khalf ? pa[d0 + 1] : pa[d0]) + dslot_a + base;
+  };
+  auto row8 = [&](const int T, unsigned mask_g, unsigned mask_n, int base_g, int base_n, unsigned boff_g, unsigned boff_n, bool more,
+                  bool pair_end) __attribute__((always_inline)) {       // T is a literal at both call sites: it folds after inlining
+    // the pair that straddles this row and the next (T = 0 only): per-lane source, weight and liveness selections
+    unsigned selA = 0u, selB = 0u, lv = 0u;
+    if (T == 0) {
+      selA = (khalf ? pa[0] + (unsigned)base_n : pa[K - 1] + (unsigned)base_g) + dslot_a;
+      selB = khalf ? (more ? b8k - (unsigned)kBTileN + boff_n : kOobN) : b8k + (unsigned)((K - 1) * kBTileN) + boff_g;
+      lv = khalf ? mask_n : mask_g;
+    }
+    auto a8_x = [&](int j) __attribute__((always_inline)) -> unsigned { return ((lv >> j) & 1u) ? selA : kOobN; };
+    const unsigned m_mm = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_g);   // scalars: the tile skips are s_cbranch, not exec masks
+    const unsigned m_x = (unsigned)__builtin_amdgcn_readfirstlane((int)(mask_g | mask_n));
 #pragma unroll
     for (int u = 0; u < K; ++u) {
       const bool last_u = (u == K - 1);
-      const bool cross = (u & 1) || last_u;              // this tap ends pair u >> 1: its FP8 MFMAs are issued here
-      const int cpp = u >> 1, npp = last_u ? 0 : (u >> 1) + 1;
-      const unsigned m_mm = (unsigned)__builtin_amdgcn_readfirstlane((int)mask_g);   // a scalar: the tile skips are s_cbranch, not exec masks
+      const bool cross = T == 0 ? ((u & 1) || last_u) : (u >= 2 && !(u & 1));   // this tap ends a pair: its FP8 MFMAs are issued here
+      const bool xrow = T == 0 && last_u;                                        // ... the pair that straddles the rows
+      const bool next_x = T == 0 && u == K - 2;                                  // the pair AFTER this one straddles the rows
       const unsigned nb0 = pa[last_u ? 0 : u + 1] + (unsigned)(last_u ? base_n : base_g);
       const unsigned bsrc = b_lane + (last_u ? boff_n : boff_g + (unsigned)((u + 1) * kBTileN));
-      const unsigned cb8 = pa8[cpp] + (unsigned)base_g;                               // this pair, tiles 2 / 3
-      const unsigned nb8 = pa8[npp] + (unsigned)(last_u ? base_n : base_g);           // next pair, tiles 0 / 1
-      const unsigned bsrc8 = pb8[npp] + (last_u ? boff_n : boff_g);
       if (R > 1 && last_u && pair_end) {
         __builtin_amdgcn_s_waitcnt(0xC07F);
         wait_vm0();
         __builtin_amdgcn_s_barrier();
       }
-      if (u == 0) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) b[0][n][0] = b[1][n][0];
+      // this pair's first tap d0 (same-row pairs) and the next pair's: (u + 1 | u + 2) in this row, the straddling pair, or the
+      // next row's first pair -- (1 | 2) after a type-0 row, (0 | 1) after a type-1 row
+      const int d0 = u - 1;
+      unsigned cb8 = 0u, nb8 = 0u, bsrc8 = 0u;
+      if (cross) {
+        if (!xrow) cb8 = a8_same(d0, (unsigned)base_g);
+        if (!next_x) {
+          const int nd0 = last_u ? (T == 0 ? 1 : 0) : u + 1;
+          nb8 = a8_same(nd0, (unsigned)(last_u ? base_n : base_g));
+          bsrc8 = b8k + (unsigned)(nd0 * kBTileN) + (last_u ? boff_n : boff_g);
+        } else {
+          bsrc8 = selB;
+        }
       }
-      uint4(&bc)[2][2] = b[u & 1];
-      uint4(&bn)[2][2] = b[(u + 1) & 1];
+      // f16 hi * W_hi, column tile by column tile: a W_hi fragment is free for the next tap's after four MFMAs, an A fragment after
+      // its second one -- every operand is single-buffered
 #pragma unroll
-      for (int n = 0; n < 2; ++n) bn[n][0] = lds128n(bsrc + n * kTileN);
+      for (int j = 0; j < 4; ++j)
+        if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) mma<DT>(acc[j][0], a[j][0], b[0][0][0]);
+      b[0][0][0] = lds128n(bsrc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) {
-          mma<DT>(acc[j][0], a[j][0], bc[0][0]);
-          mma<DT>(acc[j][1], a[j][0], bc[1][0]);
-          if (cross) {
+        if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) mma<DT>(acc[j][1], a[j][0], b[0][1][0]);
+        a[j][0] = lds128n(nb0 + j * kTileN);
+      }
+      b[0][1][0] = lds128n(bsrc + kTileN);
+      if (cross) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (__builtin_expect(((xrow ? m_x : m_mm) & (1u << j)) != 0, 1)) {
             mma8(acc[j][0], a8[j & 1], b8[0]);
             mma8(acc[j][1], a8[j & 1], b8[1]);
           }
-        }
-        a[j][0] = lds128n(nb0 + j * kTileN);
-        if (cross) {
-          const unsigned src8 = j < 2 ? cb8 + (j + 2) * kTileN : nb8 + (j - 2) * kTileN;
+          // tiles 2 / 3 of THIS pair behind tiles 0 / 1, tiles 0 / 1 of the NEXT pair behind tiles 2 / 3
+          const unsigned src8 = j < 2 ? (xrow ? a8_x(j + 2) : cb8) + (j + 2) * kTileN : (next_x ? a8_x(j - 2) : nb8) + (j - 2) * kTileN;
           a8[j & 1][0] = lds128n(src8);
           a8[j & 1][1] = lds128n(src8 + a8_d1);
         }
@@ -392,12 +416,12 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
       const unsigned nb0 = pa[0] + (unsigned)base_of(0, 0);
       const unsigned nb1 = nb0 + a_d1;
       if constexpr (X8) {
-        const unsigned nb8 = pa8[0] + (unsigned)base_of(0, 0);
+        const unsigned nb8 = a8_same(0, (unsigned)base_of(0, 0));      // row 0 is of type 0: its first pair is (0 | 1)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          b[1][n][0] = lds128n(b_lane + n * kTileN);
-          b8[n][0] = lds128n(pb8[0] + n * kTileN);
-          b8[n][1] = lds128n(pb8[0] + b8_d1 + n * kTileN);
+          b[0][n][0] = lds128n(b_lane + n * kTileN);
+          b8[n][0] = lds128n(b8k + n * kTileN);
+          b8[n][1] = lds128n(b8k + b8_d1 + n * kTileN);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j][0] = lds128n(nb0 + j * kTileN);
@@ -417,9 +441,9 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
       }
     }
     // row g = (dzi, dyi); its weights sit at LDS offset boff; the fill that keeps AHEAD slot fills in flight goes to `fslot`
-    int dzi = 0, dyi = 0, fill = AHEAD, fslot = AHEAD % NS;
+    int dzi = 0, dyi = 0, fill = AHEAD, fslot = AHEAD % NS, g = 0;
     unsigned boff = 0u;
-    for (int g = 0; g < NG; ++g) {
+    auto do_row = [&](const int T) __attribute__((always_inline)) {        // T: the row's parity (X8: its pairing type), a literal at every call
       if (g % R == 0 && fill < NSR) {      // g % R: R is 1 or 2
         stage_b(c, fill, fslot);
         ++fill;
@@ -434,9 +458,20 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
       const unsigned mask_g = mask_of(dzi, dyi), mask_n = more ? mask_of(dzn, dyn) : 0u;
       const int base_g = base_of(dzi, dyi), base_n = more ? base_of(dzn, dyn) : 0;
       const bool pair_end = (g % R == R - 1) || !more;
-      if constexpr (X8) row8(mask_g, base_g, base_n, boff, boff_n, pair_end);
+      if constexpr (X8) row8(T, mask_g, mask_n, base_g, base_n, boff, boff_n, more, pair_end);
       else row(mask_g, mask_n, base_g, base_n, boff, boff_n, pair_end);
-      dzi = dzn; dyi = dyn; boff = boff_n;
+      dzi = dzn; dyi = dyn; boff = boff_n; ++g;
+    };
+    if constexpr (X8) {
+      // rows in pairs (type 0, type 1) as straight-line code, the odd last row behind the loop: a run-time branch between the two
+      // row bodies inside the loop makes hipcc spill hundreds of registers (the accumulators pass through its merge point)
+      for (int gp = 0; gp < NG / 2; ++gp) {
+        do_row(0);
+        do_row(1);
+      }
+      do_row(0);
+    } else {
+      for (int gg = 0; gg < NG; ++gg) do_row(0);
     }
   }
   __builtin_amdgcn_s_waitcnt(0xC07F);

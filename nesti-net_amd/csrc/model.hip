@@ -1510,6 +1510,16 @@ size_t nesti_estimate_workspace_bytes(const nesti_model_t* m, int batch) {
   return est_points_bytes(m, batch) + est_neff_bytes(m, batch) + ws_layout(m, batch).total;
 }
 
+size_t nesti_estimate_workspace_bytes_for_config(const nesti_config_t* cfg, int dtype, int batch) {
+  if (!cfg || batch <= 0) return 0;
+  // the layout functions only look at the graph and the mode flags: a model shell without weights sizes exactly like the real one
+  nesti_model shell;
+  shell.cascade = dtype_cascade(dtype);
+  shell.dtype = main_dtype(dtype);
+  if (build_graph(cfg, &shell.graph, dtype_x8(dtype))) return 0;
+  return nesti_estimate_workspace_bytes(&shell, batch);
+}
+
 int nesti_estimate_normals(const nesti_model_t* m, const float* cloud_dev, int N, const int32_t* query_idx_dev, int M,
                            const double* r_abs, uint64_t seed, int query_row0, int batch, int build_grid,
                            void* grid_ws_dev, size_t grid_ws_bytes, void* ws_dev, size_t ws_bytes,

@@ -183,3 +183,10 @@ def test_tower_workspace_bytes_from_the_configuration_alone():
         assert ws("f16x3", tower) <= ws("f16x8", tower) <= ws("f16x3", tower) + 1024 * 512 * (128 + 256) * 2 and ws("f16x8c", tower) == ws("f16x8", tower)
     assert 1.5e6 < ws("f16", -1) / 1024 < 2.5e6                      # ~2 MB per query for the gating net in 16-bit
     assert ws("f16", 7) == 0 and ws("f16", -2) == 0 and ws("f16", 0, 0) == 0
+    # the whole arena of a fused-call batch from the configuration alone (cli.fit_batch): positive, monotone in the batch, the pair
+    # modes above the plain ones, the FP8 cross-term modes no smaller than their f16x3 counterparts
+    def arena(dtype, batch=4096):
+        return lib.nesti_estimate_workspace_bytes_for_config(ctypes.byref(c), DTYPES[dtype], batch)
+    assert 0 < arena("f16") < arena("f16x3") and arena("f16x3c", 32768) < arena("f16x3", 32768)   # recheck rounds on a quarter of a large batch
+    assert arena("f16x3") <= arena("f16x8") and arena("f16x3c") <= arena("f16x8c")
+    assert arena("f16", 8192) > arena("f16", 4096) and arena("f16", 0) == 0

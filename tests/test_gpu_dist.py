@@ -69,7 +69,7 @@ def test_bench_two_ranks_debug_single_device(gpu_device):
     assert d["parity"]["queries"] == 3000 and d["parity"]["one_minus_cos"]["p50"] <= 2e-5
     # the strong-scaling leg: ONE cloud's rows over the two ranks (dist.estimate_sharded), printed next to the weak figure
     assert d["strong"]["scaling"] == "strong" and d["strong"]["value"] > 0 and "ONE 6000-point cloud" in d["strong"]["workload"]
-    assert d["dtype"] == "f16x3c" and d["parity"]["meets_north_star"] and d["gate_cascade"]["rechecked"] > 0
+    assert d["dtype"] == "f16x8c" and d["parity"]["meets_north_star"] and d["gate_cascade"]["rechecked"] > 0
 
 
 def test_bench_eight_ranks_debug_single_device(gpu_device):

@@ -88,8 +88,10 @@ def test_cli_writes_reference_file_contract(dataset_dir, tmp_path, gpu_device):
 
 
 def test_cli_default_mode_calibrates_the_gate_per_shape(dataset_dir, tmp_path, gpu_device):
-    """--dtype auto = f16x3c for experts_n_est: the gate margin is calibrated on every shape (its counters are that shape's,
-    printed to log.txt), two library batches are in flight on two streams, and .normals / .experts equal the f16x3 mode's."""
+    """--dtype auto = f16x8c for experts_n_est on the 8^3 grid: the gate margin is calibrated on every shape (its counters are that
+    shape's, printed to log.txt), two library batches are in flight on two streams, .experts equal the f16x3 mode's and .normals
+    equal the f16x8 mode's bit for bit (the cascade is orthogonal to the expert arithmetic) and stay within 2.5e-6 cosine of f16x3's
+    (the FP8 cross terms of the experts' 5^3 layers, tests/test_gpu_x8.py)."""
     from nesti_net_amd import weights
     from nesti_net_amd.cli import main
     from nesti_net_amd.config import NestiConfig
@@ -106,14 +108,18 @@ def test_cli_default_mode_calibrates_the_gate_per_shape(dataset_dir, tmp_path, g
     log = open(os.path.join(out, "log.txt")).read()
     assert log.count("gate margin for shape") == 2 and log.count("two-stage gate on shape") == 2
     est = NormalEstimator(cfg, W, dtype="f16x3", device=gpu_device, batch=1000)
+    est8 = NormalEstimator(cfg, W, dtype="f16x8", device=gpu_device, batch=1000)
     for nm, n in (("shapeA", 3000), ("shapeB", 2500)):
         normals = np.loadtxt(os.path.join(out, nm + ".normals"))
         experts = np.loadtxt(os.path.join(out, nm + ".experts"))
         probs = np.loadtxt(os.path.join(out, nm + ".experts_probs"))
         assert normals.shape == (n, 3) and experts.shape == (n,) and probs.shape == (n, 7)
         n2, e2, p2 = est.estimate(load_xyz(os.path.join(dataset_dir, nm + ".xyz")))
-        assert np.array_equal(e2, experts.astype(np.int32))
-        assert np.array_equal(n2.astype(np.float64), normals)
+        n8, e8, _ = est8.estimate(load_xyz(os.path.join(dataset_dir, nm + ".xyz")))
+        assert np.array_equal(e2, experts.astype(np.int32)) and np.array_equal(e8, e2)
+        assert np.array_equal(n8.astype(np.float64), normals)
+        cos = (n2.astype(np.float64) * normals).sum(1) / (np.linalg.norm(n2.astype(np.float64), axis=1) * np.linalg.norm(normals, axis=1))
+        assert (1 - cos).max() <= 2.5e-6
         assert np.abs(p2 - probs).max() < 0.05
 
 

@@ -7,7 +7,7 @@
     input channels in inception1),
   * layer mask 0 == f16x3 bit for bit, the 3^3 layers can be added (mask 0xF) within 1e-5,
   * f16x8c == f16x8 in arg-max and normals once its gate margin is calibrated (the cascade is orthogonal to the expert arithmetic),
-and against the fp64 oracle on 256 queries (1 - cos <= 1e-5, arg-max exact outside the tie margin)."""
+and against the fp64 oracle on 96 queries (1 - cos <= 1e-5, arg-max exact outside the tie margin)."""
 import os
 
 import numpy as np
@@ -92,14 +92,14 @@ def test_x8_against_the_oracle(gpu_device):
     from oracle import mups_ref, net_ref, patches_ref
     cfg = NestiConfig()
     pts = synth.make_cloud("torus", n=20000, seed=77, noise=0.006)[0]
-    q = np.arange(0, 20000, 78)[:256]
+    q = np.arange(0, 20000, 208)[:96]
     cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
     p_d, n_d = cp.build(0, len(q))
     W = calibrate_gate(cfg, weights.synthetic_weights(cfg), p_d, n_d, device=gpu_device)
     o_pts, o_neff, _, _ = patches_ref.extract_patches(pts, q, cp.r_abs, cfg.num_point, cp.seed)
     mups_o = mups_ref.mups_assemble(o_pts, o_neff, cfg.n_scales)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    ref = [net_ref.moe_forward(mups_o[i:i + 64], W, expert_dict=cfg.expert_dict, dtype=torch.float64, top1_only=True) for i in range(0, len(q), 64)]
+    ref = [net_ref.moe_forward(mups_o[i:i + 48], W, expert_dict=cfg.expert_dict, dtype=torch.float64, top1_only=True) for i in range(0, len(q), 48)]
     ref = {k: torch.cat([r[k] for r in ref]).numpy() for k in ("probs", "expert", "normals")}
     n8, e8, _ = NestiNet(cfg, W, dtype="f16x8", device=gpu_device, max_batch=len(q))(p_d, n_d)
     srt = np.sort(ref["probs"], axis=1)
