@@ -367,20 +367,24 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
       }
       // f16 hi * W_hi, column tile by column tile: a W_hi fragment is free for the next tap's after four MFMAs, an A fragment after
       // its second one -- every operand is single-buffered
+      // three copies of the tile mask, each opaque to the compiler: otherwise it merges the repeated bit tests into vector compares
+      // (v_cndmask + v_cmp + s_andn2 per branch instead of s_bitcmp + s_cbranch)
+      unsigned m0 = m_mm, m1 = m_mm, m2 = xrow ? m_x : m_mm;
+      asm volatile("" : "+s"(m0), "+s"(m1), "+s"(m2));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) mma<DT>(acc[j][0], a[j][0], b[0][0][0]);
+        if (__builtin_expect((m0 & (1u << j)) != 0, 1)) mma<DT>(acc[j][0], a[j][0], b[0][0][0]);
       b[0][0][0] = lds128n(bsrc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (__builtin_expect((m_mm & (1u << j)) != 0, 1)) mma<DT>(acc[j][1], a[j][0], b[0][1][0]);
+        if (__builtin_expect((m1 & (1u << j)) != 0, 1)) mma<DT>(acc[j][1], a[j][0], b[0][1][0]);
         a[j][0] = lds128n(nb0 + j * kTileN);
       }
       b[0][1][0] = lds128n(bsrc + kTileN);
       if (cross) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (__builtin_expect(((xrow ? m_x : m_mm) & (1u << j)) != 0, 1)) {
+          if (__builtin_expect((m2 & (1u << j)) != 0, 1)) {
             mma8(acc[j][0], a8[j & 1], b8[0]);
             mma8(acc[j][1], a8[j & 1], b8[1]);
           }

@@ -7,11 +7,15 @@ contiguous ranges keep output order = file order -- the cloud and the weights ar
 and the only exchange is ONE all-gather of the per-shard results per shape
 (normals 3 + expert 1 + probs E floats per point, ~4.4 MB for 100k points).
 
-dtype 'f16x3c': the gather buffer carries one spare row per rank holding that rank's ``max_margin_err`` (the largest
-error its f16 gate filter has shown); after the gather every rank folds all of them into its own counter
+dtypes 'f16x3c' / 'f16x8c': the gather buffer carries one spare row per rank holding that rank's ``max_margin_err`` (the
+largest error its f16 gate filter has shown); after the gather every rank folds all of them into its own counter
 (``NestiNet.export_gate_error`` / ``import_gate_error``: two one-thread kernels, no host synchronisation, no extra
 collective), so from the next step on ALL ranks filter with the same ``tau_eff`` = 1.5 x the largest error any rank has
-measured."""
+measured.  Scope of that guarantee: the imported maximum lives in the same device counter as the rank's own
+measurements, so (a) it lasts until the counters are reset -- ``calibrate_gate_margin`` resets them for every shape, after which
+the ranks re-converge with the next gather -- and (b) ``cascade_stats()['max_margin_err']`` of a rank reads the largest error ANY
+rank has measured since the last reset, not that rank's alone.  The export runs on the caller's current stream after
+``NormalEstimator.run`` / ``run_many`` have joined their lane streams (they end with ``main.wait_stream(lane)``)."""
 import torch
 import torch.distributed as dist
 
