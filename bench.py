@@ -210,6 +210,13 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
         res["gate_margin"] = {"tau": tau, "sigmas": GATE_MARGIN_SIGMAS, "calibration_queries": int(sp.shape[0]),
                               "tau_max_minus_min_over_ranks": spread}
         del sp, sn
+    if dtype in X8:
+        # the conditioning guard of the FP8 cross-term layers: its |n| threshold from the same kind of sample (calibrate.py); every
+        # rank measures the same sample with the same arithmetic, so the thresholds agree without an exchange
+        from nesti_net_amd.calibrate import calibrate_x8_guard
+        sp, sn = clouds[0].build(0, min(1024, clouds[0].patch_count))
+        res["x8_guard_thr"] = calibrate_x8_guard(est.net, sp, sn)
+        del sp, sn
 
     def step():
         for c in clouds:
@@ -230,6 +237,8 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     sync()
     if dtype in CASCADE:
         est.net.cascade_stats(reset=True)
+    if dtype in X8:
+        est.net.x8_guard_stats(reset=True)
     if timing:
         lib.nesti_profile_enable(1)
     t0 = time.perf_counter()
@@ -247,6 +256,8 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
         lib.nesti_profile_enable(0)
     if dtype in CASCADE:
         res["cascade"] = est.net.cascade_stats()                      # rank 0's counters over the timed steps
+    if dtype in X8:
+        res["x8_guard"] = {**est.net.x8_guard_stats(), "thr_calibrated": res.get("x8_guard_thr"), "x8_layers": x8_layers if x8_layers is not None else 0xA}
     res.update({"elapsed": elapsed, "batch": est.batch, "streams": est.n_streams, "steps": steps,
                 "out": [t.cpu().numpy() for t in out]})
     if rank == 0:
@@ -448,6 +459,9 @@ def main():
                          "f16x3c: f16 hi + lo pairs with the two-stage gate -- meets the north star's parity clause "
                          "(bit-exact arg-max up to fp32 ties, 1e-5 cosine: see 'parity'); f16x3: the same without the gate filter; "
                          "f16 / bf16: plain 16-bit, faster, do NOT meet it (657 / 4 652 arg-max flips per 100k queries)")
+    ap.add_argument("--x8-layers", type=lambda v: int(v, 0), default=None,
+                    help="dtypes f16x8 / f16x8c: which expert tap layers at 8^3 take their cross terms through FP8 (library default 0xA: both 5^3 layers; "
+                         "0xE adds inception2's 3^3 layer, 0xF both 3^3 layers)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (fp32-mode rerun of rank 0's shard of cloud 0)")
@@ -518,17 +532,19 @@ def main():
     headline = not args.stream_clouds
     eff_streams = 1 if args.graph else args.streams          # a captured graph replays on one stream (--graph)
     main_run = timed_run(args, cfg, W, clouds_np, args.dtype, args.steps, args.warmup, dev, world, rank, use_pg,
-                         timing and eff_streams == 1 and not args.graph, want_shard0=not args.no_parity and args.dtype != "f32", streams=eff_streams)
+                         timing and eff_streams == 1 and not args.graph, want_shard0=not args.no_parity and args.dtype != "f32", streams=eff_streams,
+                         x8_layers=args.x8_layers)
     # per-kernel times need launches that do not overlap: a short single-stream pass of the same workload carries the roofline
     # (every rank takes part -- the pass contains the same collectives as the headline run -- but only rank 0 records events)
     # (a replayed hipGraph records no events either: with --graph the pass runs the same batches eagerly)
     roof_run = main_run
     if not args.no_kernel_timing and (main_run["streams"] > 1 or args.graph):
-        roof_run = timed_run(args, cfg, W, clouds_np, args.dtype, 2, 1, dev, world, rank, use_pg, timing, want_shard0=False, graph=False)
+        roof_run = timed_run(args, cfg, W, clouds_np, args.dtype, 2, 1, dev, world, rank, use_pg, timing, want_shard0=False, graph=False,
+                             x8_layers=args.x8_layers)
     strong = None
     if headline and (world > 1 or args.strong):
         strong = timed_run(args, cfg, W, clouds_np, args.dtype, max(2, min(args.steps, 5)), 1, dev, world, rank, use_pg, False,
-                           want_shard0=False, strong=True, streams=args.streams)
+                           want_shard0=False, strong=True, streams=args.streams, x8_layers=args.x8_layers)
     legs = {}
     if headline and not args.no_secondary and world == 1:
         # the other modes on the same workload, a few steps each, each with its own parity object against the fp32 mode
@@ -560,6 +576,13 @@ def main():
                        "weights": "synthetic seed %d" % weights.WEIGHT_SEED,
                        "routing_histogram": hist.tolist(), "parallelism": "dp%d (query rows)" % world},
         }
+        if "x8_guard" in main_run:
+            g = main_run["x8_guard"]
+            res["x8_guard"] = {**g, "rechecked_frac": g["rechecked"] / max(1, g["queries"]),
+                               "note": "FP8 cross terms in the expert tap layers of mask x8_layers (bit 0 / 1 = inception1 conv2 / conv3, 2 / 3 = inception2 "
+                                       "conv2 / conv3); an expert output with |n| < thr_eff = max(thr, 1.5 x max_dn / sqrt(2 x 2.5e-6)) is evaluated again in "
+                                       "f16x3 proper (max_dn = largest |n_x8 - n_f16x3| measured on the rows decided twice during the timed steps): "
+                                       "an un-re-evaluated query keeps 1 - cos <= 1.1e-6 against f16x3 as long as |dn| stays below max_dn"}
         if "cascade" in main_run:
             c = main_run["cascade"]
             res["gate_cascade"] = {**main_run["gate_margin"], **c, "rechecked_frac": c["rechecked"] / max(1, c["queries"]),

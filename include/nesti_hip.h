@@ -252,6 +252,31 @@ int nesti_model_set_gate_mix(nesti_model_t* m, int on);
 /* NESTI_F16X8 / NESTI_F16X8C models: which expert tap layers at 8^3 take their cross terms through FP8 (see the dtype's comment above;
  * default 0b1010, 0 = NESTI_F16X3 proper, at most 0b1111). */
 int nesti_model_set_x8_layers(nesti_model_t* m, int mask);
+/* The CONDITIONING GUARD of those models (top-1 routed calls: nesti_forward, nesti_estimate_normals[_multi], nesti_experts_forward
+ * with an expert assignment).  The FP8 residual moves an expert's raw output n by |dn| -- ~5e-5, at most 2e-4 on 100 000 queries, and
+ * independent of |n| -- and 1 - cos against the three-product result is (|dn| / |n|)^2 / 2: only outputs of very small norm can be
+ * tilted by more than the bar.  Every query whose |n| is below
+ *     thr_eff = max(thr, NESTI_X8_GUARD_WIDEN x largest |dn| measured so far / sqrt(2 x NESTI_X8_GUARD_BAR))
+ * is evaluated again by its expert in f16x3 proper and that result replaces the FP8 one (a fraction of a per cent of the queries);
+ * the rows decided twice measure |dn|, so the threshold follows the measurement like the two-stage gate's margin does, and a call
+ * whose own measurement opens a wider band re-evaluates the rows in between in NESTI_X8_GUARD_WIDEN_PASSES further passes.  An
+ * un-re-evaluated query therefore differs from f16x3 by 1 - cos <= NESTI_X8_GUARD_BAR / NESTI_X8_GUARD_WIDEN^2 as long as |dn| stays
+ * below the largest value measured.  nesti_model_set_x8_guard: thr >= 0 (default NESTI_X8_GUARD_DEFAULT; calibrate it like the gate
+ * margin: calibrate.calibrate_x8_guard), thr < 0 switches the guard off, +inf re-evaluates everything (calibration).  Must not be
+ * changed while forward calls are in flight. */
+#define NESTI_X8_GUARD_BAR 2.5e-6f
+#define NESTI_X8_GUARD_WIDEN 1.5f
+#define NESTI_X8_GUARD_WIDEN_PASSES 1
+#define NESTI_X8_GUARD_DEFAULT 0.25f
+typedef struct {
+  uint64_t queries;    /* routed queries seen since the last reset                                      */
+  uint64_t rechecked;  /* ... of them re-evaluated in f16x3                                              */
+  uint64_t dropped;    /* flagged rows NOT re-evaluated because an expert's guard list was full (0 unless the threshold is absurd) */
+  float max_dn;        /* largest |n_x8 - n_f16x3| measured on the re-evaluated rows                     */
+  float thr, thr_eff;  /* the configured threshold and the one the next call starts from                 */
+} nesti_x8_guard_stats_t;
+int nesti_model_set_x8_guard(nesti_model_t* m, float thr);
+int nesti_model_x8_guard_stats(const nesti_model_t* m, nesti_x8_guard_stats_t* out, int reset, void* stream);
 
 /* Workspace of ONE tower for `batch` queries, from the configuration alone (no device needed): tower = -1 the gating
  * net, 0..E-1 an expert.  dtype as nesti_model_create (NESTI_F16X3C: the gate figure is the f16 filter's). */

@@ -34,6 +34,13 @@ class CCascadeStats(ctypes.Structure):
                 ("widened", ctypes.c_uint64), ("widen_events", ctypes.c_uint64), ("tau_eff", ctypes.c_float)]
 
 
+class CX8GuardStats(ctypes.Structure):
+    """Mirror of ``nesti_x8_guard_stats_t``."""
+    _fields_ = [("queries", ctypes.c_uint64), ("rechecked", ctypes.c_uint64), ("dropped", ctypes.c_uint64),
+                ("max_dn", ctypes.c_float), ("thr", ctypes.c_float), ("thr_eff", ctypes.c_float)]
+
+
+X8_GUARD_BAR, X8_GUARD_WIDEN, X8_GUARD_DEFAULT = 2.5e-6, 1.5, 0.25   # NESTI_X8_GUARD_* (include/nesti_hip.h)
 GATE_WIDEN = 1.5      # NESTI_GATE_WIDEN (include/nesti_hip.h)
 GATE_WIDEN_PASSES = 3  # NESTI_GATE_WIDEN_PASSES
 
@@ -73,6 +80,8 @@ SIGNATURES = {
     "nesti_model_set_expert_mix": (_i, [_vp, _i]),
     "nesti_model_set_gate_mix": (_i, [_vp, _i]),
     "nesti_model_set_x8_layers": (_i, [_vp, _i]),
+    "nesti_model_set_x8_guard": (_i, [_vp, ctypes.c_float]),
+    "nesti_model_x8_guard_stats": (_i, [_vp, ctypes.POINTER(CX8GuardStats), _i, _vp]),
     "nesti_tower_workspace_bytes": (_sz, [_cfgp, _i, _i, _i]),
     "nesti_workspace_bytes": (_sz, [_vp, _i]),
     "nesti_model_mups_cstride": (_i, [_vp]),

@@ -78,3 +78,31 @@ def calibrate_gate_margin(net, points, n_eff, sigmas=GATE_MARGIN_SIGMAS, over_ma
     tau = max(float(sigmas) * st["sigma"], float(over_max) * st["max_margin_err"], float(floor))
     net.set_gate_margin(tau)
     return tau
+
+
+X8_GUARD_MIN_QUERIES = 256
+
+
+def calibrate_x8_guard(net, points, n_eff, floor=0.05):
+    """Set the conditioning guard's threshold of an 'f16x8' / 'f16x8c' :class:`NestiNet` (``nesti_model_set_x8_guard``) from a sample
+    of queries (``points`` [B,S*P,3] / ``n_eff`` [B,S] device tensors).
+
+    With the threshold at infinity every query of the sample is evaluated by its expert twice -- FP8 cross terms, then f16x3
+    proper -- which measures |dn| = |n_x8 - n_f16x3|, the only way the FP8 layers can tilt a normal.  |dn| does not depend on |n|
+    (corr 0.1 on the bench cloud), so the rows a later call re-evaluates keep measuring it without bias, and the LIBRARY raises its
+    threshold to ``_lib.X8_GUARD_WIDEN`` x the largest |dn| seen / sqrt(2 x ``_lib.X8_GUARD_BAR``) by itself.  The threshold set here
+    is that formula on the sample's largest |dn| (at least ``floor``); the counters are reset, so it starts un-widened.  A sample
+    of fewer than ``X8_GUARD_MIN_QUERIES`` queries leaves the library default in place.  The gate margin of an 'f16x8c' model is
+    calibrated separately (:func:`calibrate_gate_margin`); call this one afterwards -- it runs a full forward pass.  Returns thr."""
+    from . import _lib
+    if int(points.shape[0]) < X8_GUARD_MIN_QUERIES:
+        net.x8_guard_stats(reset=True)
+        net.set_x8_guard(_lib.X8_GUARD_DEFAULT)
+        return _lib.X8_GUARD_DEFAULT
+    net.x8_guard_stats(reset=True)
+    net.set_x8_guard(float("inf"))
+    net.forward(points, n_eff)
+    st = net.x8_guard_stats(reset=True)
+    thr = max(float(floor), _lib.X8_GUARD_WIDEN * st["max_dn"] / (2.0 * _lib.X8_GUARD_BAR) ** 0.5)
+    net.set_x8_guard(thr)
+    return thr

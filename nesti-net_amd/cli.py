@@ -43,6 +43,11 @@ def build_parser():
                         "the filter pass decided alone (~90 %%) are that pass's probabilities, within ~0.013 of the fp32 values; "
                         "use --dtype f16x3 when the probabilities themselves must hold 1e-4.  f16 / bf16: plain 16-bit, ~1.7x "
                         "faster, hundreds of arg-max flips per 100k points (DESIGN.md 2); f32: the exact-fp32 MFMA mode")
+    p.add_argument("--x8_layers", type=int, default=None,
+                   help="dtypes f16x8 / f16x8c: which expert tap layers at 8^3 take their cross terms through FP8 (bit 0 / 1 = inception1 "
+                        "conv2 (3^3) / conv3 (5^3), bit 2 / 3 = inception2 conv2 / conv3).  Default 10 = both 5^3 layers (1 - cos within "
+                        "~1e-6 of f16x3 on 100k queries); 15 adds the 3^3 layers (~2.5 %% faster, worst query 3.5e-6: inside the 1e-5 "
+                        "tolerance, above the 2.5e-6 bar the default is held to); 0 = f16x3c proper")
     p.add_argument("--lib_batch", type=int, default=0,
                    help="queries per library batch (0 = by dtype: 50000 for f16x3c / f16 / bf16, 25000 for the pair modes, 8192 "
                         "for f32; two such batches are in flight on two HIP streams)")
@@ -133,7 +138,10 @@ def main(argv=None):
     if fit != batch:
         printout("library batch %d -> %d rows: %.1f GB free on %s" % (batch, fit, torch.cuda.mem_get_info(device)[0] / 1e9, device))
         batch = fit
-    est = NormalEstimator(cfg, W, dtype=dtype, device=device, batch=batch, n_streams=2, subsample=FLAGS.subsample)
+    if FLAGS.x8_layers is not None and dtype not in ("f16x8", "f16x8c"):
+        raise SystemExit("--x8_layers belongs to --dtype f16x8 / f16x8c")
+    est = NormalEstimator(cfg, W, dtype=dtype, device=device, batch=batch, n_streams=2, subsample=FLAGS.subsample,
+                          x8_layers=FLAGS.x8_layers)
     printout("Model restored.")
 
     for ind, name in enumerate(dataset.shape_names):
@@ -145,6 +153,12 @@ def main(argv=None):
             from .calibrate import calibrate_gate_margin
             sp, sn = cloud.build(0, min(1024, cloud.patch_count))
             printout("gate margin for %s: tau = %.4g" % (name, calibrate_gate_margin(est.net, sp, sn)))
+            del sp, sn
+        if dtype in ("f16x8", "f16x8c"):
+            # the conditioning guard of the FP8 cross-term layers: its |n| threshold from the same sample of THIS shape
+            from .calibrate import calibrate_x8_guard
+            sp, sn = cloud.build(0, min(1024, cloud.patch_count))
+            printout("FP8 guard threshold for %s: |n| < %.4g" % (name, calibrate_x8_guard(est.net, sp, sn)))
             del sp, sn
         normals, expert, probs = est.run(cloud)
         torch.cuda.synchronize()
@@ -164,6 +178,10 @@ def main(argv=None):
             if st["widen_events"]:
                 printout("  the measured error came within a factor 1.5 of the margin: the library widened it and re-decided "
                          "%d more queries with the f16x3 gate before these files were written" % st["widened"])
+        if dtype in ("f16x8", "f16x8c"):
+            gs = est.net.x8_guard_stats()
+            printout("FP8 cross terms on %s: %d of %d expert outputs re-evaluated in f16x3 (|n| below %.4g), largest |dn| measured %.3g"
+                     % (name, gs["rechecked"], gs["queries"], gs["thr_eff"], gs["max_dn"]))
     flog.close()
     return 0
 

@@ -151,6 +151,13 @@ int launch_round_counts(const int32_t* counts, int n_lists, int cap, int n_round
 int launch_switch_finish(const float* logits, int lstride, int B, float threshold, float* probs,
                          int32_t* expert, int32_t* counts /*[2] or NULL*/, int32_t* lists /*[2][B] or NULL*/,
                          hipStream_t stream);
+// the conditioning guard of the FP8 cross-term experts (pool.hip): band of |n| for this pass, flag expert e's rows inside it, replace
+// them by their f16x3 re-evaluation and measure |dn|
+int launch_x8_guard_begin(int pass, float thr, float scale, int B, unsigned long long* gstat, float* slot, hipStream_t stream);
+int launch_x8_guard_flag(const int32_t* list, const int32_t* count_ptr, int count_cap, const float* normals, const float* slot,
+                         int32_t* glist, int32_t* gcount, int cap, unsigned long long* gstat, hipStream_t stream);
+int launch_x8_guard_fix(const float* src, int sstride, const int32_t* glist, const int32_t* gcount, int cap, float* normals,
+                        unsigned long long* gstat, hipStream_t stream);
 // build routing lists from a caller-supplied expert assignment
 int launch_route(const int32_t* expert, int B, int E, int32_t* counts, int32_t* lists,
                  hipStream_t stream);

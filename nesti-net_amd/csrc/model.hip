@@ -478,6 +478,10 @@ struct nesti_model {
   // it (include/nesti_hip.h: nesti_model_set_x8_layers)
   std::vector<nesti::PackedLayer> packed_x8;
   int x8_mask = 0;
+  // ... and their conditioning guard (pool.hip: x8_guard_*): outputs with |n| below max(x8_guard_thr, NESTI_X8_GUARD_WIDEN x largest
+  // measured |dn| / theta) are re-evaluated in f16x3 proper; gstat = the device counters (include/nesti_hip.h: nesti_x8_guard_stats_t)
+  float x8_guard_thr = NESTI_X8_GUARD_DEFAULT;
+  unsigned long long* gstat = nullptr;
   int gate_mix = 0;          // EXPERIMENT (nesti_model_set_gate_mix): the f16x3 gating passes run their tap layers single-product
   float tau = 0.25f;
   unsigned long long* cstat = nullptr;
@@ -488,6 +492,7 @@ struct nesti_model {
         if (p.bias) (void)hipFree(p.bias);
       }
     if (cstat) (void)hipFree(cstat);
+    if (gstat) (void)hipFree(gstat);
   }
 };
 
@@ -1048,7 +1053,7 @@ size_t max_tower_bytes(const nesti_model* m, int NB) {
 }
 
 struct WsLayout {
-  size_t x0, probs, expert, counts, lists, ecounts, keep, flags, fcounts, tower, total;
+  size_t x0, probs, expert, counts, lists, ecounts, glist, keep, flags, fcounts, tower, total;
 };
 WsLayout ws_layout(const nesti_model* m, int NB) {
   WsLayout L;
@@ -1059,7 +1064,9 @@ WsLayout ws_layout(const nesti_model* m, int NB) {
   L.expert = o; o += align_up((size_t)NB * 4, 256);
   L.counts = o; o += 256;
   L.lists = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
-  L.ecounts = o; o += 1024;          // [E][rounds] rows of each expert round
+  L.ecounts = o; o += 1024;          // [E][rounds] rows of each expert round; words 128 / 130-131: the conditioning guard's list length and |n| band
+  L.glist = o;
+  if (m->graph.x8) o += align_up((size_t)NB * 4, 256);   // the conditioning guard's row list (one expert at a time)
   L.keep = L.flags = L.fcounts = o;
   if (m->cascade) {   // the f16 gate's logits, the flag list, [flag count | per-round counts]
     L.keep = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
@@ -1125,14 +1132,33 @@ int gate_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_
   return launch_gate_finish(logits, lstride, B, m->graph.cfg.n_experts, probs, expert, counts, lists, stream);
 }
 
-// NB = the batch capacity the workspace was laid out for (ws_layout); ecounts = its per-(expert, round) counter block
+// NB = the batch capacity the workspace was laid out for (ws_layout); ecounts = its per-(expert, round) counter block; glist = the
+// conditioning guard's row list (x8 models, top-1 routing)
+constexpr int kGuardCountOff = 128, kGuardSlotOff = 130;      // int32 words of the ecounts block
 int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned char* tower_ws, size_t tower_bytes_,
-                 const int32_t* counts, const int32_t* lists, int32_t* ecounts, float* normals, hipStream_t stream) {
+                 const int32_t* counts, const int32_t* lists, int32_t* ecounts, int32_t* glist, float* normals, hipStream_t stream) {
   const int E = m->graph.cfg.n_experts;
   const int cap = std::min(expert_cap(NB), B), rounds = (B + cap - 1) / cap;
   prof_phase(NESTI_PHASE_EXPERTS);
   if (counts && launch_round_counts(counts, E, cap, rounds, ecounts, stream)) return 1;
   const size_t x0_row = ((size_t)1 << (3 * m->graph.gate_x0_log2S())) * mups_stride(m) * dtype_size(m->dtype);   // one query's MuPS rows
+  // the conditioning guard of the FP8 cross-term layers (pool.hip): after expert e's rows are written, those whose |n| falls inside
+  // the pass's band go through the SAME tower in f16x3 proper (one walking round of up to `cap` rows), which replaces them and
+  // measures |dn|; a second pass covers the band a larger measurement of THIS call may have opened (normally empty)
+  const bool guard = counts && glist && m->x8_mask && m->gstat && m->x8_guard_thr >= 0.f;
+  float* gslot = guard ? reinterpret_cast<float*>(ecounts + kGuardSlotOff) : nullptr;
+  int32_t* gcount = guard ? ecounts + kGuardCountOff : nullptr;
+  const float gscale = NESTI_X8_GUARD_WIDEN / sqrtf(2.f * NESTI_X8_GUARD_BAR);
+  auto guard_expert = [&](int e) -> int {
+    const Tower& T = m->graph.experts[e];
+    if (launch_x8_guard_flag(lists + (size_t)e * B, counts + e, B, normals, gslot, glist, gcount, cap, m->gstat, stream)) return 1;
+    float* out = nullptr;
+    RunCtx rc{m, cap, gcount, glist, stream, false, m->expert_mix};
+    rc.walk = true;                          // x8 = 0: the three-product loop everywhere
+    if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
+    return launch_x8_guard_fix(out, T.bufs[T.out_buf].C, glist, gcount, cap, normals, m->gstat, stream);
+  };
+  if (guard && launch_x8_guard_begin(0, m->x8_guard_thr, gscale, B, m->gstat, gslot, stream)) return 1;
   for (int e = 0; e < E; ++e) {
     const Tower& T = m->graph.experts[e];
     const int ostride = T.bufs[T.out_buf].C;
@@ -1153,6 +1179,14 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
         if (run_tower(rc, T, (const unsigned char*)X0 + (size_t)r * cap * x0_row, tower_ws, tower_bytes_, &out)) return 1;
         if (launch_scatter3(out, ostride, nullptr, nullptr, take, normals + ((size_t)e * B + (size_t)r * cap) * 3, stream)) return 1;
       }
+    }
+    if (guard && guard_expert(e)) return 1;
+  }
+  if (guard) {
+    for (int pass = 1; pass <= NESTI_X8_GUARD_WIDEN_PASSES; ++pass) {
+      if (launch_x8_guard_begin(pass, m->x8_guard_thr, gscale, B, m->gstat, gslot, stream)) return 1;
+      for (int e = 0; e < E; ++e)
+        if (guard_expert(e)) return 1;
     }
   }
   return 0;
@@ -1309,6 +1343,8 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
         if (op.aux_in_buf >= 0 && pack_layer_x8(m->graph.layers[op.layer], tt, &m->packed_x8[op.layer])) return 1;
       }
     m->x8_mask = 0xA;          // both 5^3 layers (include/nesti_hip.h: nesti_model_set_x8_layers)
+    NESTI_CHECK_HIP(hipMalloc((void**)&m->gstat, 64));
+    NESTI_CHECK_HIP(hipMemset(m->gstat, 0, 64));
   }
   if (m->cascade) {
     m->packed_fast.resize(m->graph.layers.size());
@@ -1354,6 +1390,28 @@ int nesti_model_set_x8_layers(nesti_model_t* m, int mask) {
   if (m->packed_x8.empty()) NESTI_FAIL("nesti_model_set_x8_layers: not an NESTI_F16X8 / NESTI_F16X8C model");
   if (mask < 0 || mask > 0xF) NESTI_FAIL("nesti_model_set_x8_layers: mask has four bits (inception1 conv2 / conv3, inception2 conv2 / conv3)");
   m->x8_mask = mask;
+  return 0;
+}
+
+int nesti_model_set_x8_guard(nesti_model_t* m, float thr) {
+  if (!m || !m->gstat) NESTI_FAIL("nesti_model_set_x8_guard: not an NESTI_F16X8 / NESTI_F16X8C model");
+  if (thr != thr) NESTI_FAIL("nesti_model_set_x8_guard: threshold is NaN");
+  m->x8_guard_thr = thr;
+  return 0;
+}
+
+int nesti_model_x8_guard_stats(const nesti_model_t* m, nesti_x8_guard_stats_t* out, int reset, void* stream) {
+  if (!m || !m->gstat || !out) NESTI_FAIL("nesti_model_x8_guard_stats: not an NESTI_F16X8 / NESTI_F16X8C model / null argument");
+  unsigned long long h[8];
+  NESTI_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  NESTI_CHECK_HIP(hipMemcpy(h, m->gstat, sizeof(h), hipMemcpyDeviceToHost));
+  if (reset) NESTI_CHECK_HIP(hipMemset(m->gstat, 0, 64));
+  out->queries = h[0]; out->rechecked = h[1]; out->dropped = h[3];
+  const uint32_t bits = (uint32_t)h[2];
+  memcpy(&out->max_dn, &bits, 4);
+  out->thr = m->x8_guard_thr;
+  out->thr_eff = m->x8_guard_thr < 0.f ? m->x8_guard_thr
+                                       : std::max(m->x8_guard_thr, NESTI_X8_GUARD_WIDEN * out->max_dn / sqrtf(2.f * NESTI_X8_GUARD_BAR));
   return 0;
 }
 
@@ -1459,14 +1517,15 @@ int nesti_experts_forward(const nesti_model_t* m, const void* mups_dev, const in
     lists = (int32_t*)(ws + L.lists);
     if (launch_route(expert_dev, B, m->graph.cfg.n_experts, counts, lists, st)) return 1;
   }
-  return experts_impl(m, mups_dev, B, B, ws + L.tower, L.total - L.tower, counts, lists, (int32_t*)(ws + L.ecounts), normals_out_dev, st);
+  return experts_impl(m, mups_dev, B, B, ws + L.tower, L.total - L.tower, counts, lists, (int32_t*)(ws + L.ecounts),
+                      m->graph.x8 ? (int32_t*)(ws + L.glist) : nullptr, normals_out_dev, st);
 }
 
 // gate -> routing -> experts on a MuPS tensor X0 that already sits in the workspace
 static int forward_tail(const nesti_model_t* m, const void* X0, int B, int NB, unsigned char* ws, const WsLayout& L,
                         float* normals_out_dev, int32_t* expert_out_dev, float* probs_out_dev, hipStream_t st) {
   if (m->graph.cfg.arch == NESTI_ARCH_SINGLE || m->graph.cfg.arch == NESTI_ARCH_MULTI)   // single-tower ablations: the tower's output IS n_pred (test_n_est.py:136-141)
-    return experts_impl(m, X0, B, NB, ws + L.tower, L.total - L.tower, nullptr, nullptr, nullptr, normals_out_dev, st);
+    return experts_impl(m, X0, B, NB, ws + L.tower, L.total - L.tower, nullptr, nullptr, nullptr, nullptr, normals_out_dev, st);
   float* probs = probs_out_dev ? probs_out_dev : (float*)(ws + L.probs);
   int32_t* expert = expert_out_dev ? expert_out_dev : (int32_t*)(ws + L.expert);
   int32_t* counts = (int32_t*)(ws + L.counts);
@@ -1474,7 +1533,8 @@ static int forward_tail(const nesti_model_t* m, const void* X0, int B, int NB, u
   if (m->cascade ? gate_cascade(m, X0, B, ws, L, NB, probs, expert, counts, lists, st)
                  : gate_impl(m, X0, B, ws + L.tower, L.total - L.tower, probs, expert, counts, lists, st))
     return 1;
-  return experts_impl(m, X0, B, NB, ws + L.tower, L.total - L.tower, counts, lists, (int32_t*)(ws + L.ecounts), normals_out_dev, st);
+  return experts_impl(m, X0, B, NB, ws + L.tower, L.total - L.tower, counts, lists, (int32_t*)(ws + L.ecounts),
+                      m->graph.x8 ? (int32_t*)(ws + L.glist) : nullptr, normals_out_dev, st);
 }
 
 int nesti_forward(const nesti_model_t* m, const float* points_dev, const int32_t* n_eff_dev, int B, void* ws_dev,

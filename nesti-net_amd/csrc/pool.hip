@@ -485,6 +485,84 @@ int launch_switch_finish(const float* logits, int lstride, int B, float threshol
   return 0;
 }
 
+// ---- the conditioning guard of the FP8 cross-term experts (NESTI_F16X8 / NESTI_F16X8C; model.hip: experts_impl) ---------------------
+// The FP8 residual moves an expert's output n by |dn| ~ 5e-5 (<= 2e-4 on 100 000 queries), independent of |n|; 1 - cos against the
+// three-product result is (|dn| / |n|)^2 / 2, so only outputs of very small norm can be tilted by more than the bar.  A query whose
+// |n| is below thr = widen x (largest |dn| measured so far) / theta, theta = sqrt(2 x 2.5e-6), is therefore evaluated AGAIN by its
+// expert in f16x3 proper and the result replaces the X8 one; the rows decided twice measure |dn| (it does not depend on |n|), and the
+// threshold follows the measurement like the two-stage gate's margin does.
+//   gstat (device, per model): [0] queries, [1] rows re-evaluated, [2] largest |dn| (float bits), [3] rows dropped because a list was full
+//   slot  (device, per call):  [0] lower, [1] upper end of the current pass's |n| band (floats)
+__global__ void x8_guard_begin_kernel(int pass, float thr, float scale, int B, unsigned long long* __restrict__ gstat, float* __restrict__ slot) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float hi = fmaxf(thr, scale * __uint_as_float((unsigned)gstat[2]));      // scale = widen / theta
+  if (pass == 0) {
+    slot[0] = 0.f;
+    slot[1] = hi;
+    atomicAdd(&gstat[0], (unsigned long long)B);
+  } else {
+    slot[0] = slot[1];
+    slot[1] = fmaxf(hi, slot[1]);
+  }
+}
+// expert e's routing list -> the rows whose |n| lies in the band, compacted into glist (at most cap of them)
+__global__ void x8_guard_flag_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ count_ptr, int count_cap,
+                                     const float* __restrict__ normals, const float* __restrict__ slot, int32_t* __restrict__ glist,
+                                     int32_t* __restrict__ gcount, int cap, unsigned long long* __restrict__ gstat) {
+  const int n = min(count_cap, *count_ptr);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int i = list[j];
+  const float x = normals[(size_t)i * 3], y = normals[(size_t)i * 3 + 1], z = normals[(size_t)i * 3 + 2];
+  const float r = sqrtf(x * x + y * y + z * z);
+  if (!(r >= slot[0] && r < slot[1]) && r == r) return;                            // a NaN output is re-evaluated too
+  const int pos = atomicAdd(gcount, 1);
+  if (pos < cap) glist[pos] = i;
+  else atomicAdd(&gstat[3], 1ull);
+}
+// the f16x3 results of the flagged rows replace the X8 ones; |dn| is measured on the way
+__global__ void x8_guard_fix_kernel(const float* __restrict__ src, int sstride, const int32_t* __restrict__ glist,
+                                    const int32_t* __restrict__ gcount, int cap, float* __restrict__ normals,
+                                    unsigned long long* __restrict__ gstat) {
+  const int n = min(cap, *gcount);
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0 && n > 0) atomicAdd(&gstat[1], (unsigned long long)n);
+  if (j >= n) return;
+  const long long i = glist[j];
+  float d2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float nw = src[(size_t)j * sstride + c], od = normals[i * 3 + c];
+    d2 += (nw - od) * (nw - od);
+    normals[i * 3 + c] = nw;
+  }
+  const float dn = sqrtf(d2);
+  if (dn > 0.f && dn < INFINITY) atomicMax(&gstat[2], (unsigned long long)__float_as_uint(dn));
+}
+
+int launch_x8_guard_begin(int pass, float thr, float scale, int B, unsigned long long* gstat, float* slot, hipStream_t stream) {
+  hipLaunchKernelGGL(x8_guard_begin_kernel, dim3(1), dim3(64), 0, stream, pass, thr, scale, B, gstat, slot);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int launch_x8_guard_flag(const int32_t* list, const int32_t* count_ptr, int count_cap, const float* normals, const float* slot,
+                         int32_t* glist, int32_t* gcount, int cap, unsigned long long* gstat, hipStream_t stream) {
+  if (count_cap <= 0) return 0;
+  hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, stream, gcount, 1);
+  hipLaunchKernelGGL(x8_guard_flag_kernel, dim3((count_cap + 255) / 256), dim3(256), 0, stream, list, count_ptr, count_cap, normals,
+                     slot, glist, gcount, cap, gstat);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+int launch_x8_guard_fix(const float* src, int sstride, const int32_t* glist, const int32_t* gcount, int cap, float* normals,
+                        unsigned long long* gstat, hipStream_t stream) {
+  if (cap <= 0) return 0;
+  // a walking-size grid: the list is normally a few dozen rows; a full one is walked by the same threads
+  hipLaunchKernelGGL(x8_guard_fix_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, src, sstride, glist, gcount, cap, normals, gstat);
+  NESTI_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_route(const int32_t* expert, int B, int E, int32_t* counts, int32_t* lists, hipStream_t stream) {
   if (B <= 0) return 0;
   hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, stream, counts, E);

@@ -135,6 +135,23 @@ class NestiNet:
         bit 0 / 1 = inception1 conv2 / conv3, bit 2 / 3 = inception2 conv2 / conv3; default 0b1010; 0 = f16x3 proper)."""
         _lib.check(self.lib.nesti_model_set_x8_layers(self._handle, int(mask)), "nesti_model_set_x8_layers")
 
+    def set_x8_guard(self, thr):
+        """dtype 'f16x8' / 'f16x8c': the conditioning guard's threshold on |n| (``nesti_model_set_x8_guard``): an expert output of
+        smaller norm is re-evaluated in f16x3 proper.  ``thr < 0`` switches the guard off, ``float('inf')`` re-evaluates every query
+        (what :func:`calibrate.calibrate_x8_guard` does to measure |dn|)."""
+        _lib.check(self.lib.nesti_model_set_x8_guard(self._handle, float(thr)), "nesti_model_set_x8_guard")
+
+    def x8_guard_stats(self, reset=False, stream=None):
+        """Counters of the conditioning guard since the last reset (synchronises the stream): dict with queries, rechecked,
+        dropped (flagged rows that did not fit an expert's list: 0 unless the threshold is absurd), max_dn (largest
+        |n_x8 - n_f16x3| measured on the rows decided twice), thr and thr_eff = max(thr, 1.5 x max_dn / sqrt(2 x 2.5e-6))."""
+        st = _lib.CX8GuardStats()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.nesti_model_x8_guard_stats(self._handle, ctypes.byref(st), int(bool(reset)), self._stream(stream)),
+                       "nesti_model_x8_guard_stats")
+        return {"queries": int(st.queries), "rechecked": int(st.rechecked), "dropped": int(st.dropped), "max_dn": float(st.max_dn),
+                "thr": float(st.thr), "thr_eff": float(st.thr_eff)}
+
     def set_expert_mix(self, mask):
         """EXPERIMENT: which expert tap layers run a single 16-bit product (``nesti_model_set_expert_mix``; 0 = none)."""
         _lib.check(self.lib.nesti_model_set_expert_mix(self._handle, int(mask)), "nesti_model_set_expert_mix")

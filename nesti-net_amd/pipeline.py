@@ -19,7 +19,7 @@ class NormalEstimator:
     hipGraph once and replays it; only worthwhile for small batches where launch gaps matter."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", batch=4096, seed=3627473,
-                 use_graph=False, n_streams=1, gate_margin=None, subsample="hash"):
+                 use_graph=False, n_streams=1, gate_margin=None, subsample="hash", x8_layers=None):
         self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
         # subsample='reference': balls larger than P are thinned exactly like the reference does (scipy cKDTree traversal
         # order + ONE numpy RandomState stream over all patches in visiting order, utils/pcpnet_dataset.py:304-321), on the
@@ -48,8 +48,10 @@ class NormalEstimator:
         # staging buffers and the forward workspace; with one stream that is one call per run
         self._fused = not self.use_graph and self._ref is None
         self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=1 if self._fused else self.batch)
-        if gate_margin is not None:                       # dtype 'f16x3c' only (calibrate.calibrate_gate_margin picks one)
+        if gate_margin is not None:                       # dtypes 'f16x3c' / 'f16x8c' only (calibrate.calibrate_gate_margin picks one)
             self.net.set_gate_margin(gate_margin)
+        if x8_layers is not None:                         # dtypes 'f16x8' / 'f16x8c' only (NestiNet.set_x8_layers; default 0b1010)
+            self.net.set_x8_layers(x8_layers)
         S, P, E = cfg.n_scales, cfg.num_point, max(1, cfg.n_gate_out)
         self._graph = None
         if self._fused:

@@ -39,6 +39,11 @@ for mode, batch in ((HEAD, 100000), ("f16x3", 50000)):
     if mode == HEAD:
         sp, sn = clouds[0].build(0, 1024)
         res["tau"] = calibrate_gate_margin(est.net, sp, sn)
+        if mode in ("f16x8", "f16x8c"):
+            from nesti_net_amd.calibrate import calibrate_x8_guard
+            if os.environ.get("STREAM32_X8_LAYERS"):
+                est.net.set_x8_layers(int(os.environ["STREAM32_X8_LAYERS"], 0))
+            res["x8_guard_thr"] = calibrate_x8_guard(est.net, sp, sn)
         del sp, sn
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -53,6 +58,8 @@ for mode, batch in ((HEAD, 100000), ("f16x3", 50000)):
         st["tau_eff_over_max_margin_err"] = st["tau_eff"] / st["max_margin_err"] if st["max_margin_err"] else None
         st["tau_over_max_margin_err"] = st["tau"] / st["max_margin_err"] if st["max_margin_err"] else None
         res["gate_cascade"] = st
+        if mode in ("f16x8", "f16x8c"):
+            res["x8_guard"] = est.net.x8_guard_stats()
         n_c = normals
     else:
         same = experts[HEAD] == experts["f16x3"]

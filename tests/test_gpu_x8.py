@@ -108,3 +108,113 @@ def test_x8_against_the_oracle(gpu_device):
     omc = _omc(n8.cpu().numpy()[agree], ref["normals"][agree])
     print("f16x8 vs fp64 oracle: experts", np.unique(ref["expert"]).tolist(), "1-cos max %.3g" % omc.max())
     assert omc.max() <= 1e-5
+
+
+def test_x8_prescale_follows_the_batch_norm_and_saturates_gracefully(gpu_device):
+    """The e4m3 planes' pre-scale is 2^sc with (|beta| + 8 |gamma|) 2^sc in (128, 256], from the PRODUCING layer's folded batch-norm.
+    (a) A tower whose conv1 layers have 16x larger gamma (activations 16x larger) must stay inside the bound: the scale adapts.
+    (b) Batch-norm statistics that LIE about the data (variance 1000x too small: activations ~30x the bound, most of them beyond
+    e4m3's 448 after scaling) saturate the planes: the cross terms of those elements are lost, nothing else -- the result stays
+    finite and degrades to single-product quality at worst (1 - cos of order 1e-5 .. 1e-3), it does not blow up."""
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import synth, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from nesti_net_amd.provider import CloudPatches
+    cfg = NestiConfig()
+    pts = synth.make_cloud("ellipsoid", n=20000, seed=5)[0]
+    q = np.arange(0, 20000, 10)[:2000]
+    cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
+    p_d, n_d = cp.build(0, len(q))
+    W0 = weights.synthetic_weights(cfg)
+    expert = torch.full((len(q),), 3, dtype=torch.int32, device=gpu_device)       # one expert: Expert_3
+
+    def run(W, dtype):
+        net = NestiNet(cfg, W, dtype=dtype, device=gpu_device, max_batch=len(q))
+        return net.experts(net.mups(p_d, n_d), expert).cpu().numpy()
+
+    Wa = dict(W0)
+    for blk in ("inception1", "inception2"):
+        k = blk + "Expert_3_conv1/bn/"
+        Wa[k + "gamma"] = (W0[k + "gamma"] * 16).astype(np.float32)
+        Wa[k + "beta"] = (W0[k + "beta"] * 16).astype(np.float32)
+    oa = _omc(run(Wa, "f16x8"), run(Wa, "f16x3"))
+    print("16x larger conv1 activations: 1-cos max %.3g" % oa.max())
+    assert oa.max() <= 2.5e-6
+    Wb = dict(W0)
+    for blk in ("inception1", "inception2"):
+        k = blk + "Expert_3_conv1/bn/"
+        Wb[k + "var"] = (W0[k + "var"] / 1000).astype(np.float32)
+    n8, n3 = run(Wb, "f16x8"), run(Wb, "f16x3")
+    ob = _omc(n8, n3)
+    print("batch-norm variance 1000x too small (saturating planes): 1-cos p50 %.3g max %.3g" % (np.quantile(ob, .5), ob.max()))
+    assert np.all(np.isfinite(n8)) and ob.max() <= 5e-3
+
+
+def test_x8_conditioning_guard(gpu_device):
+    """Outputs of small norm are re-evaluated in f16x3 proper (pool.hip: x8_guard_*): threshold infinity == f16x3 bit for bit and
+    measures |dn|; threshold < 0 == the bare FP8 loop; in between exactly the rows below the threshold carry f16x3's bits, the others
+    the FP8 loop's; the threshold follows the measured |dn| (thr_eff), calibrate_x8_guard sets it from a sample, and with the guard in
+    place the largest 1 - cos against f16x3 among the un-re-evaluated rows respects the bound 2.5e-6 / 1.5^2."""
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import _lib, synth, weights
+    from nesti_net_amd.calibrate import calibrate_gate, calibrate_x8_guard
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.model import NestiNet
+    from nesti_net_amd.provider import CloudPatches
+    cfg = NestiConfig()
+    N, Q = 100000, 12000
+    pts = synth.make_cloud("ellipsoid", n=N, seed=1234)[0]
+    q = np.arange(3, N, N // Q)[:Q]
+    cp = CloudPatches(pts, cfg, device=gpu_device, pidx=q)
+    p_d, n_d = cp.build(0, Q)
+    W = calibrate_gate(cfg, weights.synthetic_weights(cfg), p_d[:512], n_d[:512], device=gpu_device)
+    n3, e3, _ = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=Q)(p_d, n_d)
+    n3 = n3.cpu().numpy()
+    net = NestiNet(cfg, W, dtype="f16x8", device=gpu_device, max_batch=Q)
+    theta = (2 * _lib.X8_GUARD_BAR) ** 0.5
+    # off: the bare FP8 loop
+    net.set_x8_guard(-1.0)
+    bare = net(p_d, n_d)[0].cpu().numpy()
+    assert net.x8_guard_stats()["rechecked"] == 0
+    rb = np.linalg.norm(bare.astype(np.float64), axis=1)
+    dn_true = np.linalg.norm(bare.astype(np.float64) - n3, axis=1)
+    # infinity: every row twice
+    net.x8_guard_stats(reset=True)
+    net.set_x8_guard(float("inf"))
+    allr = net(p_d, n_d)[0].cpu().numpy()
+    st = net.x8_guard_stats(reset=True)
+    assert np.array_equal(allr, n3) and st["rechecked"] == Q and st["queries"] == Q and st["dropped"] == 0
+    assert abs(st["max_dn"] - dn_true.max()) <= 1e-6 * max(1.0, dn_true.max()) + 1e-9, (st["max_dn"], dn_true.max())
+    # a threshold in the bulk of the |n| distribution: exactly the rows below it are f16x3's
+    thr = float(np.quantile(rb, 0.2))
+    net.set_x8_guard(thr)
+    mid = net(p_d, n_d)[0].cpu().numpy()
+    st = net.x8_guard_stats(reset=True)
+    below = rb < thr
+    assert thr > _lib.X8_GUARD_WIDEN * dn_true.max() / theta          # so the measured |dn| does not widen it
+    assert st["rechecked"] == int(below.sum()) and st["dropped"] == 0 and st["thr_eff"] == pytest.approx(thr)
+    assert np.array_equal(mid[below], n3[below]) and np.array_equal(mid[~below], bare[~below])
+    # a threshold BELOW what the measured |dn| asks for: the call widens itself -- rows up to 1.5 x |dn| / theta of the error it measured
+    # in its first pass are re-evaluated in its second pass
+    small = float(np.sort(rb)[2])                                     # two rows below it
+    net.set_x8_guard(small)
+    wid = net(p_d, n_d)[0].cpu().numpy()
+    st = net.x8_guard_stats(reset=True)
+    dn_first = dn_true[rb < small].max()
+    upper = max(small, _lib.X8_GUARD_WIDEN * dn_first / theta)
+    covered = rb < upper
+    print("widening: thr %.4g -> %.4g, %d rows re-evaluated (%d below thr), thr_eff now %.4g" % (small, upper, st["rechecked"], int((rb < small).sum()), st["thr_eff"]))
+    assert st["rechecked"] >= int(covered.sum()) and np.array_equal(wid[covered], n3[covered])
+    # calibration, then the enforced bound on the rows that keep the FP8 result
+    thr_c = calibrate_x8_guard(net, p_d[:2048], n_d[:2048])
+    out = net(p_d, n_d)[0].cpu().numpy()
+    st = net.x8_guard_stats()
+    keep = ~np.all(out == n3, axis=1)
+    omc = _omc(out[keep], n3[keep])
+    print("calibrated thr %.4g, thr_eff %.4g, re-evaluated %d of %d, max 1-cos of the rest %.3g (bound %.3g)"
+          % (thr_c, st["thr_eff"], st["rechecked"], Q, omc.max(), _lib.X8_GUARD_BAR / _lib.X8_GUARD_WIDEN ** 2))
+    assert 0 < st["rechecked"] < 0.05 * Q
+    assert omc.max() <= _lib.X8_GUARD_BAR / _lib.X8_GUARD_WIDEN ** 2 * 1.05
+    with pytest.raises(Exception):
+        NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=8).set_x8_guard(0.1)
