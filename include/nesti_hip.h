@@ -51,17 +51,19 @@ enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16
  * (within ~0.013 of NESTI_F16X3's) for the queries that were not re-decided. */
 
 /* NESTI_F16X8 / NESTI_F16X8C (round 6; MODEL dtypes only, experts_n_est on the 8^3 grid): NESTI_F16X3 / NESTI_F16X3C with the two
- * CROSS terms of the pair scheme -- lo * W_hi + hi * W_lo, 2^-11 of a layer's result -- of the EXPERT towers' 5^3 tap layers at 8^3
- * (models/experts_n_est.py:258-262: conv3 of inception1 / inception2, 2/3 of an expert's multiply-accumulates) computed by one
- * block-scaled FP8 MFMA (e4m3 x e4m3, K = 64, fp32 accumulate into the same accumulator) instead of four f16 MFMAs; hi * W_hi stays
- * an exact f16 product.  The gating net -- filter AND recheck -- is untouched, so expert_out is NESTI_F16X3C's bit for bit; the
- * normals differ from NESTI_F16X3's by a residual 28x below single-product f16: max 1 - cos 1.1e-6 over the bench's 100 000
- * queries in the emulation that preceded the kernel (profiles/r06_fp8_cross_step0.txt), against the 1e-5 tolerance.  The e4m3
+ * CROSS terms of the pair scheme -- lo * W_hi + hi * W_lo, 2^-11 of a layer's result -- of the EXPERT towers' tap layers at 8^3
+ * (models/experts_n_est.py:258-262: conv2 (3^3) and conv3 (5^3) of inception1 / inception2, 86 % of an expert's multiply-accumulates)
+ * computed by one block-scaled FP8 MFMA (e4m3 x e4m3, K = 64, fp32 accumulate into the same accumulator) instead of four f16 MFMAs;
+ * hi * W_hi stays an exact f16 product.  The gating net -- filter AND recheck -- is untouched, so expert_out is NESTI_F16X3C's bit for
+ * bit.  The normals differ from NESTI_F16X3's by a residual 28x below single-product f16 (1 - cos p50 6e-10, p99 2e-8), and the
+ * queries on which that residual could matter -- expert outputs of very small norm -- are evaluated again in f16x3 proper by the
+ * conditioning guard (nesti_model_set_x8_guard below): measured over 2.38 M queries of 32 clouds, max 1 - cos 5.8e-7 against f16x3,
+ * none above 2.5e-6, 0.21 % of the outputs re-evaluated (profiles/r06_stream32_check.json), against the 1e-5 tolerance.  The e4m3
  * planes' power-of-two pre-scales come from the producing layer's folded batch-norm (|beta| + 8 |gamma|: a data-free bound on its
  * activations; larger values saturate at the format's 448 and lose only their own cross terms).
  * nesti_model_set_x8_layers picks the layers: bit 0 / 1 = inception1 conv2 (3^3) / conv3 (5^3), bit 2 / 3 = inception2 conv2 / conv3;
- * the default is 0b1010 (both 5^3 layers), 0 is NESTI_F16X3 proper.  With the 3^3 layers too the emulation's worst query reaches
- * 3.5e-6.  Must not be changed while forward calls are in flight (declared below: nesti_model_set_x8_layers). */
+ * the default is 0b1111 (all four), 0b1010 keeps to the 5^3 layers, 0 is NESTI_F16X3 proper.  Must not be changed while forward calls
+ * are in flight (declared below: nesti_model_set_x8_layers). */
 
 /* which graph nesti_model_create builds */
 enum {
@@ -250,7 +252,7 @@ int nesti_model_set_expert_mix(nesti_model_t* m, int mask);
  * exists only in measurement builds (EXTRA_CXXFLAGS=-DNESTI_EXPERIMENT_XW), the product library refuses it. */
 int nesti_model_set_gate_mix(nesti_model_t* m, int on);
 /* NESTI_F16X8 / NESTI_F16X8C models: which expert tap layers at 8^3 take their cross terms through FP8 (see the dtype's comment above;
- * default 0b1010, 0 = NESTI_F16X3 proper, at most 0b1111). */
+ * default 0b1111, 0 = NESTI_F16X3 proper). */
 int nesti_model_set_x8_layers(nesti_model_t* m, int mask);
 /* The CONDITIONING GUARD of those models (top-1 routed calls: nesti_forward, nesti_estimate_normals[_multi], nesti_experts_forward
  * with an expert assignment).  The FP8 residual moves an expert's raw output n by |dn| -- ~5e-5, at most 2e-4 on 100 000 queries, and

@@ -37,17 +37,17 @@ def build_parser():
                    help="MFMA precision mode.  auto (default): the modes that keep .normals and .experts within the reference's "
                         "tolerance (arg-max exact up to fp32 ties, 1e-5 cosine) -- f16x8c for experts_n_est on the 8^3 grid (f16 hi + lo "
                         "pairs behind the two-stage gate, whose margin is calibrated on every shape and widens itself when the measured "
-                        "error approaches it; the experts' 5^3 tap layers take their two cross terms through one FP8 MFMA: .experts "
-                        "equal f16x3c's, .normals stay within ~1e-6 cosine of f16x3's), f16x3c on the 3^3 grid, f16x3 for the other "
+                        "error approaches it; the experts' tap layers at 8^3 take their two cross terms through one FP8 MFMA and outputs of "
+                        "small norm are evaluated again in f16x3: .experts equal f16x3c's, .normals stay within ~1e-6 cosine of f16x3's), f16x3c on the 3^3 grid, f16x3 for the other "
                         "models.  NOTE: with f16x3c / f16x8c the .experts_probs rows of queries "
                         "the filter pass decided alone (~90 %%) are that pass's probabilities, within ~0.013 of the fp32 values; "
                         "use --dtype f16x3 when the probabilities themselves must hold 1e-4.  f16 / bf16: plain 16-bit, ~1.7x "
                         "faster, hundreds of arg-max flips per 100k points (DESIGN.md 2); f32: the exact-fp32 MFMA mode")
     p.add_argument("--x8_layers", type=int, default=None,
                    help="dtypes f16x8 / f16x8c: which expert tap layers at 8^3 take their cross terms through FP8 (bit 0 / 1 = inception1 "
-                        "conv2 (3^3) / conv3 (5^3), bit 2 / 3 = inception2 conv2 / conv3).  Default 10 = both 5^3 layers (1 - cos within "
-                        "~1e-6 of f16x3 on 100k queries); 15 adds the 3^3 layers (~2.5 %% faster, worst query 3.5e-6: inside the 1e-5 "
-                        "tolerance, above the 2.5e-6 bar the default is held to); 0 = f16x3c proper")
+                        "conv2 (3^3) / conv3 (5^3), bit 2 / 3 = inception2 conv2 / conv3).  Default 15 = all four (outputs of small norm are "
+                        "re-evaluated in f16x3 by the conditioning guard: 1 - cos <= 1.1e-6 against f16x3 on every other query); 10 = the "
+                        "5^3 layers only (~2 %% slower); 0 = f16x3c proper")
     p.add_argument("--lib_batch", type=int, default=0,
                    help="queries per library batch (0 = by dtype: 50000 for f16x3c / f16 / bf16, 25000 for the pair modes, 8192 "
                         "for f32; two such batches are in flight on two HIP streams)")

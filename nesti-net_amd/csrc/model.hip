@@ -1342,7 +1342,7 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
         if (op.aux_out_buf >= 0) m->packed[op.layer].x8_sc = x8_activation_exponent(m->graph.layers[op.layer], tt);
         if (op.aux_in_buf >= 0 && pack_layer_x8(m->graph.layers[op.layer], tt, &m->packed_x8[op.layer])) return 1;
       }
-    m->x8_mask = 0xA;          // both 5^3 layers (include/nesti_hip.h: nesti_model_set_x8_layers)
+    m->x8_mask = 0xF;          // all four tap layers at 8^3 (include/nesti_hip.h: nesti_model_set_x8_layers)
     NESTI_CHECK_HIP(hipMalloc((void**)&m->gstat, 64));
     NESTI_CHECK_HIP(hipMemset(m->gstat, 0, 64));
   }

@@ -50,7 +50,7 @@ class NormalEstimator:
         self.net = NestiNet(cfg, weights, dtype=dtype, device=device, max_batch=1 if self._fused else self.batch)
         if gate_margin is not None:                       # dtypes 'f16x3c' / 'f16x8c' only (calibrate.calibrate_gate_margin picks one)
             self.net.set_gate_margin(gate_margin)
-        if x8_layers is not None:                         # dtypes 'f16x8' / 'f16x8c' only (NestiNet.set_x8_layers; default 0b1010)
+        if x8_layers is not None:                         # dtypes 'f16x8' / 'f16x8c' only (NestiNet.set_x8_layers; default 0b1111)
             self.net.set_x8_layers(x8_layers)
         S, P, E = cfg.n_scales, cfg.num_point, max(1, cfg.n_gate_out)
         self._graph = None

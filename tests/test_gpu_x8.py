@@ -1,11 +1,12 @@
-"""NESTI_F16X8 / NESTI_F16X8C (round 6): the expert towers' 5^3 tap layers with their two cross terms through ONE FP8 MFMA
-(conv8n.hip X8) -- pinned to f16x3 on 10k queries of the bench's cloud shape with a calibrated gate:
+"""NESTI_F16X8 / NESTI_F16X8C (round 6): the expert towers' tap layers at 8^3 (default: all four; mask 0xA: the 5^3 ones) with their
+two cross terms through ONE FP8 MFMA (conv8n.hip X8) and the conditioning guard behind them (pool.hip: x8_guard_*) -- pinned to
+f16x3 on 10k queries of the bench's cloud shape with a calibrated gate:
   * arg-max IDENTICAL to f16x3's on every query (the gating net is untouched) and probabilities bit-identical,
-  * normals within 1 - cos <= 2.5e-6 of f16x3's on every query (the emulation that preceded the kernel predicts max ~1.1e-6 over
-    100k queries, profiles/r06_fp8_cross_step0.txt; the tolerance of the north star is 1e-5),
+  * normals within 1 - cos <= 2.5e-6 of f16x3's on every query (the emulation that preceded the kernel: profiles/r06_fp8_cross_step0.txt;
+    the tolerance of the north star is 1e-5),
   * every expert used, so all seven towers' X8 layers and their producers' e4m3 planes are exercised (Expert_6 has 42 -> 64 padded
     input channels in inception1),
-  * layer mask 0 == f16x3 bit for bit, the 3^3 layers can be added (mask 0xF) within 1e-5,
+  * layer mask 0 == f16x3 bit for bit, every layer alone and the 5^3 pair (mask 0xA) inside the same bar,
   * f16x8c == f16x8 in arg-max and normals once its gate margin is calibrated (the cascade is orthogonal to the expert arithmetic),
 and against the fp64 oracle on 96 queries (1 - cos <= 1e-5, arg-max exact outside the tie margin)."""
 import os
@@ -56,19 +57,19 @@ def test_x8_experts_pinned_to_f16x3(gpu_device):
     net8.set_x8_layers(0)
     n0, e0, _ = net8(p_d, n_d)
     assert np.array_equal(n0.cpu().numpy(), n3) and np.array_equal(e0.cpu().numpy(), e3)
-    # all four tap layers at 8^3: within the north star's tolerance (the default keeps to the 5^3 layers: 2.5e-6 bar)
-    net8.set_x8_layers(0xF)
+    # the 5^3 layers only
+    net8.set_x8_layers(0xA)
     nf, _, _ = net8(p_d, n_d)
     omc_f = _omc(nf.cpu().numpy(), n3)
-    print("mask 0xF (3^3 layers too): 1-cos p99 %.3g max %.3g" % (np.quantile(omc_f, .99), omc_f.max()))
-    assert omc_f.max() <= 1e-5
+    print("mask 0xA (5^3 layers only): 1-cos p99 %.3g max %.3g" % (np.quantile(omc_f, .99), omc_f.max()))
+    assert omc_f.max() <= 2.5e-6
     # one layer at a time: each bit alone moves the result, and stays inside the bound
     for bit in range(4):
         net8.set_x8_layers(1 << bit)
         nb, _, _ = net8(p_d[:2000], n_d[:2000])
         ob = _omc(nb.cpu().numpy(), n3[:2000])
         assert 0 < ob.max() <= 2.5e-6, (bit, ob.max())
-    net8.set_x8_layers(0xA)
+    net8.set_x8_layers(0xF)
     del net8
     # the cascade on top: f16x8c == f16x8 once the margin is calibrated
     net_c = NestiNet(cfg, W, dtype="f16x8c", device=gpu_device, max_batch=Q)
