@@ -143,6 +143,23 @@ def test_f32_path_matches_oracle_across_fixture_cloud(name, gpu_device):
     assert twice.sum() >= st["rechecked"] and (not twice.any() or perr_c[twice].max() < 1e-4)
     assert perr_c.max() < 0.05                               # unrechecked rows carry the f16 gate's probabilities
     assert st["max_margin_err"] * 1.5 <= st["tau_eff"] * (1 + 1e-6)
+    # ---- ... and in f16x8c, the headline mode since round 6 (8^3 grid): the experts' tap layers at 8^3 with their cross terms through
+    # FP8, the conditioning guard calibrated on the fixture's own queries, against the SAME fp64 oracle results ---------------------
+    if cfg.n_gaussians == 8:
+        from nesti_net_amd.calibrate import calibrate_x8_guard
+        del net_c
+        net_8 = NestiNet(cfg, W, dtype="f16x8c", device=gpu_device, max_batch=len(q))
+        calibrate_gate_margin(net_8, p_d, n_d)
+        thr8 = calibrate_x8_guard(net_8, p_d, n_d)
+        n8, e8, _ = net_8(p_d, n_d)
+        g8 = net_8.x8_guard_stats()
+        agree_8 = e8.cpu().numpy() == ref["expert"]
+        c8 = _cos(n8.cpu().numpy()[agree_8], ref["normals"][agree_8])
+        c83 = _cos(n8.cpu().numpy(), n3.cpu().numpy())
+        print(name, "f16x8c: guard thr %.4g" % thr8, g8, "1-cos max vs oracle %.3g, vs f16x3 %.3g" % ((1 - c8).max(), (1 - c83).max()))
+        assert np.array_equal(e8.cpu().numpy(), e3.cpu().numpy())      # the gate is untouched
+        assert np.all(1 - c8 < 1e-5) and np.all(1 - c83 <= 2.5e-6)
+        assert g8["dropped"] == 0 and g8["queries"] == len(q)
 
 
 @pytest.fixture(scope="module")

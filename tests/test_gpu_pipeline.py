@@ -90,8 +90,8 @@ def test_cli_writes_reference_file_contract(dataset_dir, tmp_path, gpu_device):
 def test_cli_default_mode_calibrates_the_gate_per_shape(dataset_dir, tmp_path, gpu_device):
     """--dtype auto = f16x8c for experts_n_est on the 8^3 grid: the gate margin is calibrated on every shape (its counters are that
     shape's, printed to log.txt), two library batches are in flight on two streams, .experts equal the f16x3 mode's and .normals
-    equal the f16x8 mode's bit for bit (the cascade is orthogonal to the expert arithmetic) and stay within 2.5e-6 cosine of f16x3's
-    (the FP8 cross terms of the experts' 5^3 layers, tests/test_gpu_x8.py)."""
+    equal the f16x8 mode's bit for bit (the cascade is orthogonal to the expert arithmetic; same guard threshold) and stay within
+    2.5e-6 cosine of f16x3's (the FP8 cross terms of the experts' tap layers at 8^3 behind the conditioning guard, tests/test_gpu_x8.py)."""
     from nesti_net_amd import weights
     from nesti_net_amd.cli import main
     from nesti_net_amd.config import NestiConfig
@@ -115,7 +115,12 @@ def test_cli_default_mode_calibrates_the_gate_per_shape(dataset_dir, tmp_path, g
         probs = np.loadtxt(os.path.join(out, nm + ".experts_probs"))
         assert normals.shape == (n, 3) and experts.shape == (n,) and probs.shape == (n, 7)
         n2, e2, p2 = est.estimate(load_xyz(os.path.join(dataset_dir, nm + ".xyz")))
-        n8, e8, _ = est8.estimate(load_xyz(os.path.join(dataset_dir, nm + ".xyz")))
+        # the command line calibrates the conditioning guard on the first 1024 queries of every shape (cli.py): the same here
+        from nesti_net_amd.calibrate import calibrate_x8_guard
+        cloud8 = est8.prepare(load_xyz(os.path.join(dataset_dir, nm + ".xyz")))
+        sp, sn = cloud8.build(0, min(1024, cloud8.patch_count))
+        calibrate_x8_guard(est8.net, sp, sn)
+        n8, e8, _ = [t.cpu().numpy() for t in est8.run(cloud8)]
         assert np.array_equal(e2, experts.astype(np.int32)) and np.array_equal(e8, e2)
         assert np.array_equal(n8.astype(np.float64), normals)
         cos = (n2.astype(np.float64) * normals).sum(1) / (np.linalg.norm(n2.astype(np.float64), axis=1) * np.linalg.norm(normals, axis=1))
