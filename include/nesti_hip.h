@@ -268,7 +268,9 @@ int nesti_model_set_x8_layers(nesti_model_t* m, int mask);
  * changed while forward calls are in flight. */
 #define NESTI_X8_GUARD_BAR 2.5e-6f
 #define NESTI_X8_GUARD_WIDEN 1.5f
+#ifndef NESTI_X8_GUARD_WIDEN_PASSES
 #define NESTI_X8_GUARD_WIDEN_PASSES 1
+#endif
 #define NESTI_X8_GUARD_DEFAULT 0.25f
 typedef struct {
   uint64_t queries;    /* routed queries seen since the last reset                                      */
@@ -404,7 +406,10 @@ enum { NESTI_PROF_CONV8_K5 = 0,   /* conv8n_kernel, 5^3 taps at 8^3             
        NESTI_PROF_ONE_BY_ONE = 3, /* conv_igemm_kernel, 1x1x1 layers (+ fused avg-pool) and FC      */
        NESTI_PROF_MUPS = 4, NESTI_PROF_POOL = 5, NESTI_PROF_PATCHES = 6, NESTI_PROF_CATEGORIES = 7 };
 enum { NESTI_PHASE_INPUT = 0,     /* search grid, ball query, MuPS                                  */
-       NESTI_PHASE_GATE = 1, NESTI_PHASE_RECHECK = 2, NESTI_PHASE_EXPERTS = 3, NESTI_PROF_PHASES = 4 };
+       NESTI_PHASE_GATE = 1, NESTI_PHASE_RECHECK = 2, NESTI_PHASE_EXPERTS = 3,
+       NESTI_PHASE_GUARD = 4,     /* the conditioning guard's f16x3 re-evaluations (NESTI_F16X8 / NESTI_F16X8C); its first pass overlaps
+                                   * the experts on an auxiliary stream, so its launch durations are not wall time                  */
+       NESTI_PROF_PHASES = 5 };
 int nesti_profile_enable(int on);
 int nesti_profile_read(double* ms /*[NESTI_PROF_PHASES * NESTI_PROF_CATEGORIES]*/,
                        long long* launches /*[NESTI_PROF_PHASES * NESTI_PROF_CATEGORIES]*/);

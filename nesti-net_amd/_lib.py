@@ -108,7 +108,7 @@ SIGNATURES = {
 }
 PROF_CATEGORIES = ("conv8_k5", "conv8_k3", "taps_4_2", "one_by_one_fc", "mups", "pool", "patches")   # NESTI_PROF_*
 PROF_CONV = PROF_CATEGORIES[:4]
-PROF_PHASES = ("input", "gate", "recheck", "experts")                                               # NESTI_PHASE_*
+PROF_PHASES = ("input", "gate", "recheck", "experts", "guard")                                      # NESTI_PHASE_*
 
 
 def profile_read(lib):

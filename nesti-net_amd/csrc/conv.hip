@@ -765,7 +765,7 @@ int launch_one_w(const ConvParams& p, hipStream_t stream) {
   }
   const int groups = (p.m_tiles + 7) / 8;
   const unsigned n_blocks = (unsigned)(groups * 8 * p.n_tiles);
-  dim3 grid(WALK ? std::min(n_blocks, kWalkGrid) : n_blocks), block(kThreads);
+  dim3 grid(WALK ? std::min(n_blocks, p.walk > 1 ? (unsigned)p.walk : kWalkGrid) : n_blocks), block(kThreads);
   hipLaunchKernelGGL((conv_igemm_kernel<DT, TN, KPIPE, X3, WALK, X2>), grid, block, lds, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;

@@ -405,7 +405,7 @@ int launch_conv4n_one_w(const ConvParams& p, hipStream_t stream) {
   }
   const int groups = (p.m_tiles + 7) / 8;
   const unsigned n_blocks = (unsigned)(groups * 8 * p.n_tiles);
-  dim3 grid(WALK ? std::min(n_blocks, kWalkGrid) : n_blocks), block(kThreads4);
+  dim3 grid(WALK ? std::min(n_blocks, p.walk > 1 ? (unsigned)p.walk : kWalkGrid) : n_blocks), block(kThreads4);
   hipLaunchKernelGGL((conv4n_kernel<DT, K, X3, WALK>), grid, block, lds4<K>(), stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;

@@ -587,7 +587,7 @@ int launch_conv8n_one_w(const ConvParams& p, hipStream_t stream) {
   }
   const int groups = (p.m_tiles + 7) / 8;
   const unsigned n_blocks = (unsigned)(groups * 8 * 2 * p.n_tiles);
-  dim3 grid(WALK ? std::min(n_blocks, kWalkGrid) : n_blocks), block(kThreadsN);
+  dim3 grid(WALK ? std::min(n_blocks, p.walk > 1 ? (unsigned)p.walk : kWalkGrid) : n_blocks), block(kThreadsN);
   hipLaunchKernelGGL((conv8n_kernel<DT, K, MODE, WALK>), grid, block, lds, stream, p);
   NESTI_CHECK_HIP(hipGetLastError());
   return 0;

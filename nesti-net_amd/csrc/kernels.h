@@ -61,7 +61,8 @@ struct ConvParams {
   // A launch that is probably EMPTY (a later round of a routing / flag list walk, a widening pass of the two-stage gate: the row
   // count sits in device memory) is made with a small fixed grid whose workgroups WALK the tiles (tile = blockIdx.x, += gridDim.x,
   // bounded by the live row count): an empty launch then costs a few hundred workgroups instead of one per tile of the capacity
-  // (a full-capacity grid of early-exiting workgroups costs ~1.1 ns each: 0.11 ms for 100k).  0 = one tile per workgroup.
+  // (a full-capacity grid of early-exiting workgroups costs ~1.1 ns each: 0.11 ms for 100k).  0 = one tile per workgroup; 1 = kWalkGrid
+  // workgroups; > 1 = that many (a multiple of 8): the conditioning guard's towers see a few dozen rows and use 64.
   int walk;
   // NESTI_BF16X3 / NESTI_F16X3 (common.h): in_cstride / in_coff / out_cstride / mp_cstride and n_chunks are PHYSICAL (two planes per
   // 64-channel group); out_coff / out_coff2 stay logical and every 16-bit store goes through split_col + two planes.

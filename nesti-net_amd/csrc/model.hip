@@ -16,6 +16,16 @@
 
 #include "kernels.h"
 
+#ifndef NESTI_GUARD_WALK_GRID     // measurement builds may override it (scripts/ab_guard.sh); 1 = the default walking grid (kWalkGrid)
+#define NESTI_GUARD_WALK_GRID 64
+#endif
+#ifndef NESTI_GATE_WIDEN_WALK_GRID    // the two-stage gate's widening passes hold at most a few hundred rows (normally none)
+#define NESTI_GATE_WIDEN_WALK_GRID 1
+#endif
+#ifndef NESTI_GUARD_WIDEN_WALK_GRID   // the guard's widening pass is normally EMPTY: its launches only have to be dispatched and retire
+#define NESTI_GUARD_WIDEN_WALK_GRID 8
+#endif
+
 namespace nesti {
 
 // ------------------------------------------------------------------------------------------
@@ -481,7 +491,15 @@ struct nesti_model {
   // ... and their conditioning guard (pool.hip: x8_guard_*): outputs with |n| below max(x8_guard_thr, NESTI_X8_GUARD_WIDEN x largest
   // measured |dn| / theta) are re-evaluated in f16x3 proper; gstat = the device counters (include/nesti_hip.h: nesti_x8_guard_stats_t)
   float x8_guard_thr = NESTI_X8_GUARD_DEFAULT;
+  int x8_guard_walk = NESTI_GUARD_WALK_GRID;   // workgroups of the guard towers' walking launches (kernels.h: ConvParams::walk)
   unsigned long long* gstat = nullptr;
+  // a guard tower sees a handful of rows, so it is latency-bound (one workgroup walks a layer's whole K loop: ~3 ms per tower): expert
+  // e's guard runs on ONE auxiliary stream while the caller's stream goes on with expert e + 1 (events in both directions).  One
+  // stream, not E: with more streams than hardware queues (4 by default) the event waits of one stream block the kernels of another
+  // that shares its queue -- measured: E side streams cost the two-stream mode 3 %
+  mutable hipStream_t gstream = nullptr;
+  mutable hipEvent_t gev_done[NESTI_MAX_EXPERTS] = {}, gev_join = nullptr;
+  mutable std::mutex gmu;
   int gate_mix = 0;          // EXPERIMENT (nesti_model_set_gate_mix): the f16x3 gating passes run their tap layers single-product
   float tau = 0.25f;
   unsigned long long* cstat = nullptr;
@@ -493,6 +511,9 @@ struct nesti_model {
       }
     if (cstat) (void)hipFree(cstat);
     if (gstat) (void)hipFree(gstat);
+    if (gstream) (void)hipStreamDestroy(gstream);
+    for (auto& ev : gev_done) if (ev) (void)hipEventDestroy(ev);
+    if (gev_join) (void)hipEventDestroy(gev_join);
   }
 };
 
@@ -938,7 +959,7 @@ struct RunCtx {
                                  // MuPS tensor it reads keeps the model's pair layout (only the hi plane is read)
   int mix = 0;                   // expert towers in a pair mode: the layers whose packed_mix bit is set here run single-product
   bool zero_lo = false;          // experiment (gate_mix == 2): every layer writes its outputs rounded to 16 bits (lo plane = 0)
-  bool walk = false;             // this pass over a device-side list is probably empty (a later round, a widening pass): its conv
+  int walk = 0;                  // this pass over a device-side list is probably empty (a later round, a widening pass): its conv
                                  // launches use small walking grids (kernels.h: ConvParams::walk)
   int x8 = 0;                    // expert towers of an NESTI_F16X8 / NESTI_F16X8C model: nesti_model::x8_mask (which tap layers run the
                                  // FP8 cross-term loop; their block's conv1 then also writes the e4m3 planes)
@@ -1001,7 +1022,7 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
-      p.walk = rc.walk ? 1 : 0;
+      p.walk = rc.walk;
       const int cat = conv_category(d, pl);
       const int tok = prof_begin(cat, rc.stream);
       // (a mixed layer is a plain f16 / bf16 kernel inside a pair-mode tower: kernel_dtype is the same element type either way)
@@ -1044,6 +1065,8 @@ int cascade_rounds(int NB) { return (NB + cascade_cap(NB) - 1) / cascade_cap(NB)
 // rounds over its routing list (rounds beyond the list's length launch empty grids: ~0.2 % of a 100k batch); the workspace of a
 // batch is then set by the gating net alone and a whole 100k-point cloud is one library batch in every mode but f16x3 / f32.
 int expert_cap(int NB) { return NB <= 8192 ? NB : (int)align_up((size_t)(NB + 3) / 4, 256); }
+// rows of ONE expert the conditioning guard can re-evaluate per pass (a fraction of a per cent of a batch are flagged at all)
+int guard_cap(int NB) { return std::min(expert_cap(NB), 2048); }
 
 size_t max_tower_bytes(const nesti_model* m, int NB) {
   size_t t = m->cascade ? std::max(tower_bytes(m->graph.gate, NB, NESTI_F16), tower_bytes(m->graph.gate, cascade_cap(NB), m->dtype))
@@ -1064,9 +1087,9 @@ WsLayout ws_layout(const nesti_model* m, int NB) {
   L.expert = o; o += align_up((size_t)NB * 4, 256);
   L.counts = o; o += 256;
   L.lists = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
-  L.ecounts = o; o += 1024;          // [E][rounds] rows of each expert round; words 128 / 130-131: the conditioning guard's list length and |n| band
+  L.ecounts = o; o += 1024;          // [E][rounds] rows of each expert round; words 128-135 / 140-141: the conditioning guard's list lengths and |n| band
   L.glist = o;
-  if (m->graph.x8) o += align_up((size_t)NB * 4, 256);   // the conditioning guard's row list (one expert at a time)
+  if (m->graph.x8) o += align_up((size_t)NESTI_MAX_EXPERTS * guard_cap(NB) * 4, 256);   // the conditioning guard's row lists, one per expert
   L.keep = L.flags = L.fcounts = o;
   if (m->cascade) {   // the f16 gate's logits, the flag list, [flag count | per-round counts]
     L.keep = o; o += align_up((size_t)NB * NESTI_MAX_EXPERTS * 4, 256);
@@ -1108,7 +1131,7 @@ int gate_cascade(const nesti_model* m, const void* X0, int B, unsigned char* ws,
     const int32_t* round_counts = fcounts + (pass == 0 ? kRoundCountsOff : kWidenRoundsOff);
     for (int r = 0; r < rounds; ++r) {
       RunCtx exact{m, cap, round_counts + r, flag_list + (size_t)r * cap, stream};
-      exact.walk = pass >= 1 || r >= 1;      // round 0 of pass 0 holds the flagged rows; everything after it is normally empty
+      exact.walk = pass >= 1 ? NESTI_GATE_WIDEN_WALK_GRID : r >= 1 ? 1 : 0;   // round 0 of pass 0 holds the flagged rows; everything after it is normally empty
       if (run_tower(exact, m->graph.gate, X0, tower_ws, tower_bytes_, &logits)) return 1;
       if (launch_gate_recheck(logits, lstride, flag_list + (size_t)r * cap, round_counts + r, cap, E, keep, probs, expert,
                               m->cstat, stream))
@@ -1134,7 +1157,7 @@ int gate_impl(const nesti_model* m, const void* X0, int B, unsigned char* tower_
 
 // NB = the batch capacity the workspace was laid out for (ws_layout); ecounts = its per-(expert, round) counter block; glist = the
 // conditioning guard's row list (x8 models, top-1 routing)
-constexpr int kGuardCountOff = 128, kGuardSlotOff = 130;      // int32 words of the ecounts block
+constexpr int kGuardCountOff = 128, kGuardSlotOff = 140;      // int32 words of the ecounts block: [E] list lengths, the |n| band
 int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned char* tower_ws, size_t tower_bytes_,
                  const int32_t* counts, const int32_t* lists, int32_t* ecounts, int32_t* glist, float* normals, hipStream_t stream) {
   const int E = m->graph.cfg.n_experts;
@@ -1142,21 +1165,33 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
   prof_phase(NESTI_PHASE_EXPERTS);
   if (counts && launch_round_counts(counts, E, cap, rounds, ecounts, stream)) return 1;
   const size_t x0_row = ((size_t)1 << (3 * m->graph.gate_x0_log2S())) * mups_stride(m) * dtype_size(m->dtype);   // one query's MuPS rows
-  // the conditioning guard of the FP8 cross-term layers (pool.hip): after expert e's rows are written, those whose |n| falls inside
-  // the pass's band go through the SAME tower in f16x3 proper (one walking round of up to `cap` rows), which replaces them and
-  // measures |dn|; a second pass covers the band a larger measurement of THIS call may have opened (normally empty)
+  // the conditioning guard of the FP8 cross-term layers (pool.hip): once expert e's rows are written, those whose |n| falls inside the
+  // pass's band go through the SAME tower in f16x3 proper, which replaces them and measures |dn|; a second pass covers the band a
+  // larger measurement of THIS call may have opened (normally empty).  A guard tower sees a handful of rows, so it is latency-bound
+  // (~3 ms: one workgroup walks a layer's whole K loop): in the first pass expert e's guard runs on the model's auxiliary stream, in its
+  // own slice of the tower workspace, while the caller's stream goes on with expert e + 1
   const bool guard = counts && glist && m->x8_mask && m->gstat && m->x8_guard_thr >= 0.f;
+  const int gcap = std::min(guard_cap(NB), B);
   float* gslot = guard ? reinterpret_cast<float*>(ecounts + kGuardSlotOff) : nullptr;
-  int32_t* gcount = guard ? ecounts + kGuardCountOff : nullptr;
+  int32_t* gcount = guard ? ecounts + kGuardCountOff : nullptr;                 // [E]
   const float gscale = NESTI_X8_GUARD_WIDEN / sqrtf(2.f * NESTI_X8_GUARD_BAR);
-  auto guard_expert = [&](int e) -> int {
+  size_t main_bytes = 0, guard_bytes = 0;
+  for (int e = 0; e < E && guard; ++e) {
+    main_bytes = std::max(main_bytes, align_up(tower_bytes(m->graph.experts[e], cap, m->dtype), 256));
+    guard_bytes = std::max(guard_bytes, tower_bytes(m->graph.experts[e], gcap, m->dtype));
+  }
+  const bool side = guard && m->gstream && main_bytes + guard_bytes <= tower_bytes_;      // else: on the caller's stream, one after the other
+  std::unique_lock<std::mutex> glk(m->gmu, std::defer_lock);
+  if (side) glk.lock();                        // the auxiliary stream and the events are the model's: one call enqueues on them at a time
+  auto guard_expert = [&](int e, hipStream_t st, unsigned char* arena, size_t arena_bytes, int walk_grid) -> int {
     const Tower& T = m->graph.experts[e];
-    if (launch_x8_guard_flag(lists + (size_t)e * B, counts + e, B, normals, gslot, glist, gcount, cap, m->gstat, stream)) return 1;
+    int32_t* gl = glist + (size_t)e * gcap;
+    if (launch_x8_guard_flag(lists + (size_t)e * B, counts + e, B, normals, gslot, gl, gcount + e, gcap, m->gstat, st)) return 1;
     float* out = nullptr;
-    RunCtx rc{m, cap, gcount, glist, stream, false, m->expert_mix};
-    rc.walk = true;                          // x8 = 0: the three-product loop everywhere
-    if (run_tower(rc, T, X0, tower_ws, tower_bytes_, &out)) return 1;
-    return launch_x8_guard_fix(out, T.bufs[T.out_buf].C, glist, gcount, cap, normals, m->gstat, stream);
+    RunCtx rc{m, gcap, gcount + e, gl, st, false, m->expert_mix};
+    rc.walk = walk_grid;                       // x8 = 0: the three-product loop everywhere; a small walking grid (a few dozen rows)
+    if (run_tower(rc, T, X0, arena, arena_bytes, &out)) return 1;
+    return launch_x8_guard_fix(out, T.bufs[T.out_buf].C, gl, gcount + e, gcap, normals, m->gstat, st);
   };
   if (guard && launch_x8_guard_begin(0, m->x8_guard_thr, gscale, B, m->gstat, gslot, stream)) return 1;
   for (int e = 0; e < E; ++e) {
@@ -1180,13 +1215,29 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
         if (launch_scatter3(out, ostride, nullptr, nullptr, take, normals + ((size_t)e * B + (size_t)r * cap) * 3, stream)) return 1;
       }
     }
-    if (guard && guard_expert(e)) return 1;
+    if (guard) {
+      prof_phase(NESTI_PHASE_GUARD);
+      if (side) {
+        NESTI_CHECK_HIP(hipEventRecord(m->gev_done[e], stream));
+        NESTI_CHECK_HIP(hipStreamWaitEvent(m->gstream, m->gev_done[e], 0));
+        if (guard_expert(e, m->gstream, tower_ws + main_bytes, tower_bytes_ - main_bytes, m->x8_guard_walk)) return 1;
+      } else if (guard_expert(e, stream, tower_ws, tower_bytes_, m->x8_guard_walk)) {
+        return 1;
+      }
+      prof_phase(NESTI_PHASE_EXPERTS);
+    }
   }
   if (guard) {
+    if (side) {
+      NESTI_CHECK_HIP(hipEventRecord(m->gev_join, m->gstream));
+      NESTI_CHECK_HIP(hipStreamWaitEvent(stream, m->gev_join, 0));
+      glk.unlock();
+    }
+    prof_phase(NESTI_PHASE_GUARD);
     for (int pass = 1; pass <= NESTI_X8_GUARD_WIDEN_PASSES; ++pass) {
       if (launch_x8_guard_begin(pass, m->x8_guard_thr, gscale, B, m->gstat, gslot, stream)) return 1;
       for (int e = 0; e < E; ++e)
-        if (guard_expert(e)) return 1;
+        if (guard_expert(e, stream, tower_ws, tower_bytes_, NESTI_GUARD_WIDEN_WALK_GRID)) return 1;
     }
   }
   return 0;
@@ -1345,6 +1396,9 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
     m->x8_mask = 0xF;          // all four tap layers at 8^3 (include/nesti_hip.h: nesti_model_set_x8_layers)
     NESTI_CHECK_HIP(hipMalloc((void**)&m->gstat, 64));
     NESTI_CHECK_HIP(hipMemset(m->gstat, 0, 64));
+    NESTI_CHECK_HIP(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
+    NESTI_CHECK_HIP(hipEventCreateWithFlags(&m->gev_join, hipEventDisableTiming));
+    for (int e = 0; e < cfg->n_experts; ++e) NESTI_CHECK_HIP(hipEventCreateWithFlags(&m->gev_done[e], hipEventDisableTiming));
   }
   if (m->cascade) {
     m->packed_fast.resize(m->graph.layers.size());

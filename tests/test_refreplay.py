@@ -78,3 +78,46 @@ def test_traversal_order_is_the_order_of_tree_indices():
                 if i < 8:
                     one = tree.query_ball_point(c[i], float(rad))
                     assert one == ball
+
+
+def test_prefetch_stops_its_worker_when_the_consumer_fails():
+    """pipeline.NormalEstimator._prefetch (the producer / consumer of both reference-order paths): whatever fails, the
+    worker thread is stopped and joined before the error propagates, and the estimator refuses further reference-order runs --
+    the shared random stream would no longer line up with the reference's."""
+    import threading
+    import types
+    from nesti_net_amd.pipeline import NormalEstimator
+    made, consumed = [], []
+
+    def make(i, span):
+        made.append(i)
+        return i * 10
+
+    def consume_ok(i, span, item, release):
+        consumed.append((i, item))
+        release()
+
+    me = types.SimpleNamespace(_ref_failed=False)
+    before = threading.active_count()
+    NormalEstimator._prefetch(me, list(range(5)), make, consume_ok)
+    assert consumed == [(i, i * 10) for i in range(5)] and not me._ref_failed and threading.active_count() == before
+
+    def consume_bad(i, span, item, release):
+        release()
+        if i == 1:
+            raise RuntimeError("upload failed")
+
+    made.clear()
+    with pytest.raises(RuntimeError, match="upload failed"):
+        NormalEstimator._prefetch(me, list(range(50)), make, consume_bad)
+    assert me._ref_failed and threading.active_count() == before and len(made) < 50      # the producer did not run on
+
+    def make_bad(i, span):
+        if i == 2:
+            raise ValueError("sampler failed")
+        return i
+
+    me2 = types.SimpleNamespace(_ref_failed=False)
+    with pytest.raises(ValueError, match="sampler failed"):
+        NormalEstimator._prefetch(me2, list(range(6)), make_bad, consume_ok)
+    assert me2._ref_failed and threading.active_count() == before
