@@ -42,7 +42,23 @@ for mode in ("hash", "reference", "reference_host"):
     outs[mode] = [t.cpu().numpy() for t in out]
     res[mode] = {"seconds_per_cloud": dt, "normals_per_sec": N / dt, "batch": est.batch}
     if mode == "reference":
-        sizes = cloud.count_balls(0, N).cpu().numpy()
+        # the two kernels of the mode on their own (hipEvents): ball sizes of all rows, reference-order rows of one batch
+        from nesti_net_amd.refsample import RefStream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        cloud.count_balls(0, N)
+        ev[0].record(); sizes_d = cloud.count_balls(0, N); ev[1].record()
+        sizes = sizes_d.cpu().numpy()
+        nb = min(N, 25088)
+        t0 = time.perf_counter()
+        picks, offs = RefStream(3627473).picks(sizes[:nb].ravel(), cfg.num_point)
+        t_replay = time.perf_counter() - t0
+        pk, of = torch.from_numpy(picks.view(np.int16).copy()).to(dev), torch.from_numpy(offs.copy()).to(dev)
+        cloud.build_reference_order(0, nb, pk, of)
+        ev[2].record(); cloud.build_reference_order(0, nb, pk, of); ev[3].record()
+        torch.cuda.synchronize()
+        res["kernels"] = {"patches_count_kernel_ms_per_100k": ev[0].elapsed_time(ev[1]) * 1e5 / N,
+                          "patches_ref_kernel_ms_per_100k": ev[2].elapsed_time(ev[3]) * 1e5 / nb,
+                          "host_replay_s_per_100k": t_replay * 1e5 / nb, "picks_MB_per_100k": picks.nbytes * 1e5 / nb / 1e6}
         res["ball_sizes"] = {"max": sizes.max(0).tolist(), "mean": sizes.mean(0).round(1).tolist(),
                              "over_full_frac": (sizes > cfg.num_point).mean(0).round(4).tolist(), "sum_over_full": int(sizes[sizes > cfg.num_point].sum())}
     print(mode, res[mode], flush=True)

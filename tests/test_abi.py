@@ -190,3 +190,22 @@ def test_tower_workspace_bytes_from_the_configuration_alone():
     assert 0 < arena("f16") < arena("f16x3") and arena("f16x3c", 32768) < arena("f16x3", 32768)   # recheck rounds on a quarter of a large batch
     assert arena("f16x3") <= arena("f16x8") and arena("f16x3c") <= arena("f16x8c")
     assert arena("f16", 8192) > arena("f16", 4096) and arena("f16", 0) == 0
+
+
+def test_x8_dtypes_are_refused_where_they_do_not_apply():
+    """NESTI_F16X8 / NESTI_F16X8C: experts_n_est on the 8^3 grid only -- refused at the argument check (before any device call) for
+    the single-tower models and for the 3^3 grid; the setters refuse a null model."""
+    import ctypes
+    import nesti_net_amd  # noqa: F401
+    from nesti_net_amd import _lib
+    from nesti_net_amd.config import ARCH_SINGLE, DTYPES, NestiConfig
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    dummy = (_lib.CTensor * 1)()
+    for cfg in (NestiConfig(patch_radius=[0.05], n_experts=1, expert_dict={0: [0]}, arch=ARCH_SINGLE), NestiConfig(n_gaussians=3)):
+        c = cfg.to_c()
+        for dt in ("f16x8", "f16x8c"):
+            assert lib.nesti_model_create(ctypes.byref(c), dummy, 0, DTYPES[dt], ctypes.byref(h)) != 0
+            msg = lib.nesti_last_error().decode()
+            assert "F16X8" in msg or "two-stage gate" in msg, msg
+    assert lib.nesti_model_set_x8_layers(None, 0xF) != 0 and lib.nesti_model_set_x8_guard(None, ctypes.c_float(0.1)) != 0
