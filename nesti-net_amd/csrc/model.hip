@@ -1180,7 +1180,9 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
     main_bytes = std::max(main_bytes, align_up(tower_bytes(m->graph.experts[e], cap, m->dtype), 256));
     guard_bytes = std::max(guard_bytes, tower_bytes(m->graph.experts[e], gcap, m->dtype));
   }
-  const bool side = guard && m->gstream && main_bytes + guard_bytes <= tower_bytes_;      // else: on the caller's stream, one after the other
+  // (a stream that is being captured into a hipGraph keeps everything on itself: the guard then runs on the caller's stream, one
+  // tower after the other, like it does when the two workspace slices do not fit)
+  const bool side = guard && m->gstream && main_bytes + guard_bytes <= tower_bytes_ && !prof_capturing(stream);
   std::unique_lock<std::mutex> glk(m->gmu, std::defer_lock);
   if (side) glk.lock();                        // the auxiliary stream and the events are the model's: one call enqueues on them at a time
   auto guard_expert = [&](int e, hipStream_t st, unsigned char* arena, size_t arena_bytes, int walk_grid) -> int {

@@ -206,15 +206,18 @@ def test_four_scale_filter_pass_reads_both_channel_groups(gpu_device):
         assert torch.equal(a, b)
 
 
-def test_product_path_batches_graph_and_stream_modes_agree(case, gpu_device):
+@pytest.mark.parametrize("dtype", ["f16x3c", "f16x8c"])
+def test_product_path_batches_graph_and_stream_modes_agree(case, gpu_device, dtype):
     """nesti_estimate_normals with a ragged tail, the per-batch Python loop, a captured hipGraph and run_many: the same
-    bits (each query's result depends on neither its batch nor its position in the flag list)."""
+    bits (each query's result depends on neither its batch nor its position in the flag list).  f16x8c: the same with the FP8
+    cross-term experts and their conditioning guard (default threshold; inside a captured graph the guard runs on the captured
+    stream instead of the model's auxiliary one)."""
     from nesti_net_amd.pipeline import NormalEstimator
     cfg, W, pts, q, points, n_eff, ref, n_all, p16, e16, pfl, efl = case
     sub = q[:2500]
     outs = []
     for kw in ({"batch": 2500}, {"batch": 1000}, {"batch": 1024, "use_graph": True}, {"batch": 900, "n_streams": 2}):
-        est = NormalEstimator(cfg, W, dtype="f16x3c", device=gpu_device, gate_margin=0.3, **kw)
+        est = NormalEstimator(cfg, W, dtype=dtype, device=gpu_device, gate_margin=0.3, **kw)
         outs.append(est.estimate(pts, pidx=sub))
         if kw == {"batch": 1000}:
             cloud = est.prepare(pts, pidx=sub)
