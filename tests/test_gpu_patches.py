@@ -175,3 +175,31 @@ def test_reference_order_gpu_equals_the_host_sampler_on_a_dense_cloud(gpu_device
     b = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=700, subsample="reference_host").estimate(pts, pidx=q)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_reference_order_falls_back_to_the_host_for_balls_beyond_the_lds_sort(gpu_device):
+    """A shape whose balls exceed the kernel's LDS sort (16 384 points) goes through the host sampler instead -- both draw from ONE
+    native stream object, so a normal shape AFTER it still lines up with the all-host run."""
+    from nesti_net_amd import _lib, synth, weights
+    from nesti_net_amd.config import NestiConfig
+    from nesti_net_amd.pipeline import NormalEstimator
+    from nesti_net_amd.provider import CloudPatches
+    cfg = NestiConfig()
+    rs = np.random.RandomState(3)
+    blob = (rs.randn(30000, 3) * 0.01).astype(np.float32)                      # 30k points in a tiny blob ...
+    far = np.array([[40.0, 0, 0], [-40.0, 0, 0]], np.float32)                  # ... and two outliers that stretch the bounding box
+    dense = np.concatenate([blob, far])
+    q = np.arange(0, 30000, 500)[:48]
+    cp = CloudPatches(dense, cfg, device=gpu_device, pidx=q)
+    sizes = cp.count_balls(0, len(q)).cpu().numpy()
+    assert sizes.max() > _lib.load().nesti_patches_ref_max_ball()
+    normal = synth.make_cloud("torus", n=20000, seed=8)[0]
+    qn = np.arange(0, 20000, 100)[:200]
+    W = weights.synthetic_weights(cfg)
+    outs = {}
+    for mode in ("reference", "reference_host"):
+        est = NormalEstimator(cfg, W, dtype="f16", device=gpu_device, batch=32, subsample=mode)
+        outs[mode] = (est.estimate(dense, pidx=q), est.estimate(normal, pidx=qn))
+    for a, b in zip(outs["reference"], outs["reference_host"]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
