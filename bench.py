@@ -95,7 +95,8 @@ def cpu_baseline(cfg, W, pts, routing_frac):
     points, n_eff, _, _ = patches_ref.extract_patches(pts, np.arange(n_patch), r_abs, cfg.num_point, 3627473, tree)
     t_patch = (time.time() - t) / n_patch
     t = time.time()
-    mups = mups_ref.mups_assemble(points[:n_mups], n_eff[:n_mups], cfg.n_scales, dtype=np.float32)
+    mups_threads = min(cores, n_mups // 4)
+    mups = mups_ref.mups_assemble(points[:n_mups], n_eff[:n_mups], cfg.n_scales, dtype=np.float32, workers=mups_threads)
     t_mups = (time.time() - t) / n_mups
     mups = np.concatenate([mups] * (n_net // n_mups))[:n_net]
     mt = torch.as_tensor(mups)
@@ -120,9 +121,9 @@ def cpu_baseline(cfg, W, pts, routing_frac):
             "ms_per_query": {"ball_query_1_thread": t_patch * 1e3, "mups_numpy_fp32": t_mups * 1e3, "gate": t_gate * 1e3,
                              "experts": [x * 1e3 for x in t_exp]},
             "sample": "oracle/ on the same 100k cloud: scipy ball query %d queries (1 thread, like the reference's workers=0) + "
-                      "numpy MuPS fp32 %d queries + torch-CPU fp32 gate and each of the 7 experts on %d queries (%d threads, "
+                      "numpy MuPS fp32 %d queries (%d threads over chunks of 4) + torch-CPU fp32 gate and each of the 7 experts on %d queries (%d threads, "
                       "batches of %d); value = gate + routed expert (the work the GPU path does), value_all7_experts = the "
-                      "reference's evaluate-all-7 behaviour" % (n_patch, n_mups, n_net, cores, chunk)}
+                      "reference's evaluate-all-7 behaviour" % (n_patch, n_mups, mups_threads, n_net, cores, chunk)}
 
 
 def mups_leg(points, steps, warmup, cfg, dev):

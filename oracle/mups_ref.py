@@ -19,6 +19,8 @@ The four TF-only lines (``:693-702``, ``:722-729``, ``:738-740``) remain transcr
 
 All file:line citations are relative to the reference tree.
 """
+import os
+
 import numpy as np
 
 
@@ -97,7 +99,7 @@ def mups_literal(points, w, mu, sigma, n_eff, dtype=np.float64, posterior=True, 
 
 
 def mups_assemble(points, n_eff, n_scales, grid_n=8, variance=0.0156, dtype=np.float64,
-                  fn=None, chunk=4):
+                  fn=None, chunk=4, workers=None):
     """``models/experts_n_est.py:59-76``: per-scale 3DmFV -> reshape [B,20,R,R,R]
     -> transpose [B,R,R,R,20] -> concat on channels.  Returns [B,R,R,R,20*S]."""
     fn = fn or mups_literal
@@ -107,12 +109,23 @@ def mups_assemble(points, n_eff, n_scales, grid_n=8, variance=0.0156, dtype=np.f
     B = points.shape[0]
     P = points.shape[1] // n_scales
     out = np.empty((B, grid_n, grid_n, grid_n, 20 * n_scales), dtype)
-    for b0 in range(0, B, chunk):
+
+    def one(b0):
         sl = slice(b0, min(B, b0 + chunk))
         for s in range(n_scales):
             fv = fn(points[sl, s * P:(s + 1) * P], w, mu, sig, n_eff[sl, s], dtype=dtype)
             fv = fv.reshape(fv.shape[0], -1, grid_n, grid_n, grid_n)   # :71
             out[sl, ..., 20 * s:20 * (s + 1)] = np.transpose(fv, (0, 2, 3, 4, 1))  # :72
+    # the chunks are independent (every query's rows are its own): a few threads over them change nothing but the wall time
+    # (numpy releases the GIL inside the large elementwise passes; ~0.3 GB of temporaries per thread)
+    workers = max(1, min(workers if workers is not None else 16, os.cpu_count() or 1, (B + chunk - 1) // chunk))
+    if workers == 1:
+        for b0 in range(0, B, chunk):
+            one(b0)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(one, range(0, B, chunk)))
     return out
 
 
