@@ -182,6 +182,9 @@ def main(argv=None):
             gs = est.net.x8_guard_stats()
             printout("FP8 cross terms on %s: %d of %d expert outputs re-evaluated in f16x3 (|n| below %.4g), largest |dn| measured %.3g"
                      % (name, gs["rechecked"], gs["queries"], gs["thr_eff"], gs["max_dn"]))
+            if gs["dropped"]:
+                printout("  WARNING: %d flagged outputs did not fit the guard's lists and keep their FP8-cross-term values: the "
+                         "1 - cos <= 2.5e-6 bound against f16x3 is not established for them (use --dtype f16x3c for this shape)" % gs["dropped"])
     flog.close()
     return 0
 
