@@ -265,7 +265,9 @@ int nesti_model_set_x8_layers(nesti_model_t* m, int mask);
  * un-re-evaluated query therefore differs from f16x3 by 1 - cos <= NESTI_X8_GUARD_BAR / NESTI_X8_GUARD_WIDEN^2 as long as |dn| stays
  * below the largest value measured.  nesti_model_set_x8_guard: thr >= 0 (default NESTI_X8_GUARD_DEFAULT; calibrate it like the gate
  * margin: calibrate.calibrate_x8_guard), thr < 0 switches the guard off, +inf re-evaluates everything (calibration).  Must not be
- * changed while forward calls are in flight. */
+ * changed while forward calls are in flight.  Because thr_eff follows what the model has measured so far, WHICH rows are re-evaluated
+ * (hence the last bits of a few normals near the threshold, never the expert index) depends on the order and partition of the batches
+ * a model has seen since its counters were last reset (nesti_model_x8_guard_stats with reset = 1). */
 #define NESTI_X8_GUARD_BAR 2.5e-6f
 #define NESTI_X8_GUARD_WIDEN 1.5f
 #ifndef NESTI_X8_GUARD_WIDEN_PASSES
