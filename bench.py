@@ -48,6 +48,8 @@ MAX_BATCH = {"bf16x3": 50000, "f16x3": 50000, "f16x8": 50000, "f32": 8192}
 PRODUCTS = {"bf16": 1, "f16": 1, "f32": 1, "bf16x3": 3, "f16x3": 3, "f16x8": 3}   # MFMA products per multiply
 CASCADE = ("f16x3c", "f16x8c")        # the two-stage gate
 X8 = ("f16x8", "f16x8c")              # FP8 cross terms in the experts' 5^3 tap layers: per row of 5 taps 5 f16 MFMAs + 3 FP8 MFMAs of K = 64,
+X8_DEFAULT_FORMAT = 6                 # the library's default form of the cross terms (include/nesti_hip.h: nesti_model_set_x8_format)
+X6_PRODUCTS = 1.5                     # FP6 form: per tap pair 2 f16 MFMAs + 1 FP6 MFMA of K = 64 that runs 8 passes like ONE of them
 X8_K5_PRODUCTS = 2.0                  # (flat pairing: half an FP8 instruction per tap) each counted as TWO f16 instructions -- its pipe time at the nominal
                                       # 2x rate: 2.0 f16-equivalents per multiply instead of 3
 
@@ -182,7 +184,7 @@ def mups_leg(points, steps, warmup, cfg, dev):
 
 
 def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, use_pg, timing, want_shard0=True, strong=False,
-              streams=1, graph=None, x8_layers=None):
+              streams=1, graph=None, x8_layers=None, x8_format=None):
     """W warm-up steps, then exactly ``steps`` timed steps between barrier + synchronize pairs; max over ranks.
     ``strong``: a step is ONE cloud (clouds_np[0]) whose rows are sharded over the ranks (dist.estimate_sharded).
     Returns the elapsed seconds, the kernel-time table (rank 0), the last cloud's gathered results, this rank's
@@ -200,6 +202,10 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     est = NormalEstimator(cfg, W, dtype=dtype, device=dev, batch=batch, use_graph=graph, n_streams=streams)
     if x8_layers is not None:          # which expert tap layers take their cross terms through FP8 (include/nesti_hip.h: nesti_model_set_x8_layers)
         est.net.set_x8_layers(x8_layers)
+    if dtype in X8:                    # e4m3 with one scale per layer, or block-scaled e2m3 (nesti_model_set_x8_format; the library's default: 6)
+        x8_format = x8_format if x8_format is not None else getattr(args, "x8_format", None)
+        if x8_format is not None:
+            est.net.set_x8_format(x8_format)
     clouds = [est.prepare(p) for p, _ in clouds_np]          # inputs resident in HBM before timing
     res = {}
     if dtype in CASCADE:
@@ -261,7 +267,8 @@ def timed_run(args, cfg, W, clouds_np, dtype, steps, warmup, dev, world, rank, u
     if dtype in CASCADE:
         res["cascade"] = est.net.cascade_stats()                      # rank 0's counters over the timed steps
     if dtype in X8:
-        res["x8_guard"] = {**est.net.x8_guard_stats(), "thr_calibrated": res.get("x8_guard_thr"), "x8_layers": x8_layers if x8_layers is not None else 0xF}
+        res["x8_guard"] = {**est.net.x8_guard_stats(), "thr_calibrated": res.get("x8_guard_thr"), "x8_layers": x8_layers if x8_layers is not None else 0xF,
+                           "x8_format": x8_format if x8_format is not None else X8_DEFAULT_FORMAT}
     res.update({"elapsed": elapsed, "batch": est.batch, "streams": est.n_streams, "steps": steps,
                 "out": [t.cpu().numpy() for t in out]})
     if rank == 0:
@@ -313,6 +320,7 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
     peak = PEAK_TFLOPS[dtype]
     cas = run.get("cascade")
     x8_all = bool(run.get("x8_guard", {}).get("x8_layers", 0) & 0x5)      # the 3^3 layers run the FP8 form too
+    x8_fmt6 = run.get("x8_guard", {}).get("x8_format", 8) == 6             # ... in the FP6 form
     # (phase, MFMA products per multiply, queries that went through it)
     if dtype in CASCADE:
         phases = [("gate", 1, cas["queries"]), ("recheck", 3, cas["rechecked"]), ("experts", 3, rank0_pts)]
@@ -335,7 +343,7 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
         alg = 2.0 * (per_pt(k, 1, "gate") + per_pt(k, 1, "experts")) * rank0_pts
         # (f16x3c: the filter pass's one-tap layers multiply by the exact pair-packed weights -- two products per multiply)
         issued = sum(2.0 * (2 if (dtype in CASCADE and ph == "gate" and name == "one_by_one_fc") else
-                            X8_K5_PRODUCTS if (dtype in X8 and ph == "experts" and (name == "conv8_k5" or (name == "conv8_k3" and x8_all))) else prod) *
+                            (X6_PRODUCTS if x8_fmt6 else X8_K5_PRODUCTS) if (dtype in X8 and ph == "experts" and (name == "conv8_k5" or (name == "conv8_k3" and x8_all))) else prod) *
                      per_pt(k, 2, "experts" if ph == "experts" else "gate") * q for ph, prod, q in phases)
         issued_sum += issued
         by_kernel[name] = {"ms_per_step": t_ms / steps, "launches_per_step": n / steps,
@@ -467,6 +475,8 @@ def main():
                          "f16x3c: f16 hi + lo pairs with the two-stage gate -- meets the north star's parity clause "
                          "(bit-exact arg-max up to fp32 ties, 1e-5 cosine: see 'parity'); f16x3: the same without the gate filter; "
                          "f16 / bf16: plain 16-bit, faster, do NOT meet it (657 / 4 652 arg-max flips per 100k queries)")
+    ap.add_argument("--x8-format", type=int, default=None, choices=[6, 8],
+                    help="dtypes f16x8 / f16x8c: the cross terms as block-scaled FP6 e2m3 (6, the library's default) or FP8 e4m3 (8)")
     ap.add_argument("--x8-layers", type=lambda v: int(v, 0), default=None,
                     help="dtypes f16x8 / f16x8c: which expert tap layers at 8^3 take their cross terms through FP8 (library default 0xF: all four; "
                          "0xA = the 5^3 layers only)")
@@ -562,10 +572,10 @@ def main():
             if dt != args.dtype:
                 legs[key] = (dt, st, timed_run(args, cfg, W, clouds_np, dt, st, 1, dev, world, rank, use_pg, timing,
                                                want_shard0=not args.no_parity, graph=False))
-        if args.dtype == "f16x8c" and args.x8_layers is None:
-            # for comparison: only the 5^3 tap layers through FP8 (mask 0xA; the default since the conditioning guard exists is 0xF)
-            legs["x8_k5_only_mode"] = ("f16x8c", 2, timed_run(args, cfg, W, clouds_np, "f16x8c", 2, 1, dev, world, rank, use_pg, timing,
-                                                              want_shard0=not args.no_parity, graph=False, x8_layers=0xA))
+        if args.dtype == "f16x8c" and args.x8_layers is None and args.x8_format in (None, 6):
+            # for comparison: the same mode with its cross terms in FP8 e4m3 (the form the mode was introduced with)
+            legs["x8_e4m3_mode"] = ("f16x8c", 2, timed_run(args, cfg, W, clouds_np, "f16x8c", 2, 1, dev, world, rank, use_pg, timing,
+                                                           want_shard0=not args.no_parity, graph=False, x8_format=8))
 
     if rank == 0:
         elapsed = main_run["elapsed"]

@@ -254,6 +254,12 @@ int nesti_model_set_gate_mix(nesti_model_t* m, int on);
 /* NESTI_F16X8 / NESTI_F16X8C models: which expert tap layers at 8^3 take their cross terms through FP8 (see the dtype's comment above;
  * default 0b1111, 0 = NESTI_F16X3 proper). */
 int nesti_model_set_x8_layers(nesti_model_t* m, int mask);
+/* ... and in which format: 8 = OCP e4m3 with one power-of-two scale per layer and operand (above), 6 = OCP e2m3 (FP6) with one scale per
+ * 16-channel block of a row, taken from the block's largest |hi| and stored beside the elements (the instruction runs FP6 at twice the
+ * FP8 rate; |lo 2^11| <= |hi| element by element, so one scale serves a block's lo and hi halves; the residual is ~1.2x e4m3's and
+ * the conditioning guard below bounds its effect exactly as it does for e4m3).  The model holds both packings; must not be changed
+ * while forward calls are in flight; recalibrate the guard after a change. */
+int nesti_model_set_x8_format(nesti_model_t* m, int bits);
 /* The CONDITIONING GUARD of those models (top-1 routed calls: nesti_forward, nesti_estimate_normals[_multi], nesti_experts_forward
  * with an expert assignment).  The FP8 residual moves an expert's raw output n by |dn| -- ~5e-5, at most 2e-4 on 100 000 queries, and
  * independent of |n| -- and 1 - cos against the three-product result is (|dn| / |n|)^2 / 2: only outputs of very small norm can be

@@ -80,6 +80,7 @@ SIGNATURES = {
     "nesti_model_set_expert_mix": (_i, [_vp, _i]),
     "nesti_model_set_gate_mix": (_i, [_vp, _i]),
     "nesti_model_set_x8_layers": (_i, [_vp, _i]),
+    "nesti_model_set_x8_format": (_i, [_vp, _i]),
     "nesti_model_set_x8_guard": (_i, [_vp, ctypes.c_float]),
     "nesti_model_x8_guard_stats": (_i, [_vp, ctypes.POINTER(CX8GuardStats), _i, _vp]),
     "nesti_tower_workspace_bytes": (_sz, [_cfgp, _i, _i, _i]),

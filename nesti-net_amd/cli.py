@@ -43,6 +43,9 @@ def build_parser():
                         "the filter pass decided alone (~90 %%) are that pass's probabilities, within ~0.013 of the fp32 values; "
                         "use --dtype f16x3 when the probabilities themselves must hold 1e-4.  f16 / bf16: plain 16-bit, ~1.7x "
                         "faster, hundreds of arg-max flips per 100k points (DESIGN.md 2); f32: the exact-fp32 MFMA mode")
+    p.add_argument("--x8_format", type=int, default=None, choices=[6, 8],
+                   help="dtypes f16x8 / f16x8c: the experts' cross terms as block-scaled FP6 e2m3 (6, the default: half the matrix-pipe time of "
+                        "FP8 for ~1.15x its residual, bounded by the same conditioning guard) or FP8 e4m3 (8)")
     p.add_argument("--x8_layers", type=int, default=None,
                    help="dtypes f16x8 / f16x8c: which expert tap layers at 8^3 take their cross terms through FP8 (bit 0 / 1 = inception1 "
                         "conv2 (3^3) / conv3 (5^3), bit 2 / 3 = inception2 conv2 / conv3).  Default 15 = all four (outputs of small norm are "
@@ -138,10 +141,12 @@ def main(argv=None):
     if fit != batch:
         printout("library batch %d -> %d rows: %.1f GB free on %s" % (batch, fit, torch.cuda.mem_get_info(device)[0] / 1e9, device))
         batch = fit
-    if FLAGS.x8_layers is not None and dtype not in ("f16x8", "f16x8c"):
-        raise SystemExit("--x8_layers belongs to --dtype f16x8 / f16x8c")
+    if (FLAGS.x8_layers is not None or FLAGS.x8_format is not None) and dtype not in ("f16x8", "f16x8c"):
+        raise SystemExit("--x8_layers / --x8_format belong to --dtype f16x8 / f16x8c")
     est = NormalEstimator(cfg, W, dtype=dtype, device=device, batch=batch, n_streams=2, subsample=FLAGS.subsample,
                           x8_layers=FLAGS.x8_layers)
+    if FLAGS.x8_format is not None:
+        est.net.set_x8_format(FLAGS.x8_format)          # before the guard is calibrated per shape below
     printout("Model restored.")
 
     for ind, name in enumerate(dataset.shape_names):

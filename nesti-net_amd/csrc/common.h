@@ -163,6 +163,30 @@ __device__ __forceinline__ void store_aux8_8(unsigned char* aux_row, int col, co
   store_aux8_4(aux_row, col + 4, f1.x, f1.y, f1.z, f1.w, mul_lo, mul_hi);
 }
 
+// The FP6 form of the same side-buffer chunk (kernels.h: ConvParams::x8_fmt == 6): 16 consecutive channels of one row -> 32 e2m3 elements
+// under ONE power-of-two scale + that scale as an E8M0 byte.  v_cvt_scalef32_2xpk16_fp6_f32 writes src0[i] to slot 2i and src1[i] to slot
+// 2i + 1, divides by `scale`, rounds to nearest even and saturates at +-7.5 (scripts/fp6_probe.hip).  `col` = logical column, multiple of 16.
+typedef float f32x16c_t __attribute__((ext_vector_type(16)));
+typedef unsigned u32x6c_t __attribute__((ext_vector_type(6)));
+__device__ __forceinline__ void store_aux6_16(unsigned char* aux_row, int col, const float4& f0, const float4& f1, const float4& f2, const float4& f3) {
+  const float v[16] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w, f3.x, f3.y, f3.z, f3.w};
+  f32x16c_t lo, hi;
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float h = f16_bits_to_f32(f32_to_f16_bits(v[i]));
+    hi[i] = h;
+    lo[i] = (v[i] - h) * 2048.f;
+    amax = fmaxf(amax, fabsf(h));
+  }
+  int sb = (int)(__float_as_uint(amax) >> 23) - 2;       // the largest element lands in [4, 8) (7.5 < x < 8 saturates)
+  sb = sb < 1 ? 1 : sb;                                   // an all-zero chunk: any scale
+  const u32x6c_t r = __builtin_amdgcn_cvt_scalef32_2xpk16_fp6_f32(lo, hi, __uint_as_float((unsigned)sb << 23));
+  unsigned char* dst = aux_row + (col >> 6) * (2 * kSplitGroup) + (col & (kSplitGroup - 1));
+  *reinterpret_cast<uint4*>(dst) = make_uint4(r[0], r[1], r[2], r[3]);
+  *reinterpret_cast<uint4*>(dst + kSplitGroup) = make_uint4(r[4], r[5], (unsigned)sb, 0u);
+}
+
 // the pair modes as store types (mups.hip): 16-bit elements, two planes
 template <> struct Elem<NESTI_BF16X3> : Elem<NESTI_BF16> {};
 template <> struct Elem<NESTI_F16X3> : Elem<NESTI_F16> {};

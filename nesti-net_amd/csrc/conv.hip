@@ -633,9 +633,23 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
           if (gr < total_rows) {
             const float4 v4 = *reinterpret_cast<const float4*>(smem + row * kPoolStride + cg * 16);
             cvt_store(out_b, gr * p.out_cstride, out_col0 + nh * 64 + cg * 4, v4);
-            if (p.aux8_out)       // the e4m3 planes of conv1's outputs for the FP8 cross terms of the block's tap layers (conv8n.hip X8)
+            if (p.aux8_out && p.x8_fmt != 6)   // the e4m3 planes of conv1's outputs for the FP8 cross terms of the block's tap layers (conv8n.hip X8)
               store_aux8_4(reinterpret_cast<unsigned char*>(p.aux8_out) + gr * p.aux8_stride, n_local * TN + nh * 64 + cg * 4,
                            v4.x, v4.y, v4.z, v4.w, aux_mul_lo, aux_mul_hi);
+          }
+        }
+        if (p.aux8_out && p.x8_fmt == 6) {     // the FP6 form: one thread = one row's 16-channel chunk (its block scale needs all 16)
+#pragma unroll 2
+          for (int it = 0; it < 512 * 4 / kThreads; ++it) {
+            const int item = it * kThreads + tid;
+            const int row = item >> 2, c16 = item & 3;
+            const long long gr = r0 + row;
+            if (gr < total_rows) {
+              const unsigned char* src = smem + row * kPoolStride + c16 * 64;
+              store_aux6_16(reinterpret_cast<unsigned char*>(p.aux8_out) + gr * p.aux8_stride, n_local * TN + nh * 64 + c16 * 16,
+                            *reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 16),
+                            *reinterpret_cast<const float4*>(src + 32), *reinterpret_cast<const float4*>(src + 48));
+            }
           }
         }
       }
@@ -701,9 +715,21 @@ __device__ __forceinline__ void conv_igemm_tile(const ConvParams& p, const unsig
           const long long gr = r0 + tile_row(remap, log2S, wave, mi, row);
           if (gr < total_rows) {
             store_act8<E>(out_b, gr * p.out_cstride, out_col0 + nh * 64 + cpos * 8, f0, f1, p.split);
-            if (p.aux8_out && !second)
+            if (p.aux8_out && !second && p.x8_fmt != 6)
               store_aux8_8(reinterpret_cast<unsigned char*>(p.aux8_out) + gr * p.aux8_stride, n_local * TN + nh * 64 + cpos * 8, f0, f1,
                            aux_mul_lo, aux_mul_hi);
+          }
+        }
+        if (p.aux8_out && !second && p.x8_fmt == 6) {      // the FP6 form: 4 lanes x 16 channels = one 64-channel row segment
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int row = it * 16 + (lane >> 2), c16 = lane & 3;
+            const unsigned char* src = scratch + row * kPoolStride + c16 * 64;
+            const long long gr = r0 + tile_row(remap, log2S, wave, mi, row);
+            if (gr < total_rows)
+              store_aux6_16(reinterpret_cast<unsigned char*>(p.aux8_out) + gr * p.aux8_stride, n_local * TN + nh * 64 + c16 * 16,
+                            *reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 16),
+                            *reinterpret_cast<const float4*>(src + 32), *reinterpret_cast<const float4*>(src + 48));
           }
         }
       }

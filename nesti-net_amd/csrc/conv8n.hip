@@ -86,13 +86,30 @@ __device__ __forceinline__ uint4 lds128n(unsigned addr) {
   return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// X6: the second 16 bytes of an FP6 block hold two data dwords, the scale byte's dword and padding.  Read as 8 + 4 bytes the six data
+// dwords of an operand are a 16-byte and an 8-byte result, which hipcc allocates as ONE six-register tuple; read as 16 + 16 it assembles
+// the tuple with two v_mov per operand in front of every instruction (a forced eight-register tuple spills instead: measured, -3.5 %)
+typedef unsigned u32x2n_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x2n_t* lds_u32x2n_ptr;
+typedef const __attribute__((address_space(3))) unsigned* lds_u32n_ptr;
+template <bool X6>
+__device__ __forceinline__ uint4 lds_hi16n(unsigned addr) {
+  if constexpr (X6) {
+    const u32x2n_t d = *(lds_u32x2n_ptr)(size_t)addr;
+    const unsigned sc = *(lds_u32n_ptr)(size_t)(addr + 8u);
+    return make_uint4(d.x, d.y, sc, 0u);
+  } else {
+    return lds128n(addr);
+  }
+}
+
 template <int K> constexpr int lds_bytes_n() { return kAOffN + 8 * (4 + (K - 1) / 2) * kTileN; }
 
 typedef int i32x8n_t __attribute__((ext_vector_type(8)));
 
-template <int DT, int K, int MODE>     // MODE 0: plain, 1: the pair K loop (X3), 2: f16 hi * W_hi + FP8 cross terms (X8)
+template <int DT, int K, int MODE>     // MODE 0: plain, 1: the pair K loop (X3), 2: f16 hi * W_hi + FP8 cross terms (X8), 3: the same with FP6 blocks (X6)
 __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned bid, const int tid_in) {
-  constexpr bool X3 = MODE == 1, X8 = MODE == 2;
+  constexpr bool X3 = MODE == 1, X8 = MODE >= 2, X6 = MODE == 3;
   static_assert(!X8 || DT == NESTI_F16, "the FP8 cross-term loop is an f16 pair-mode variant");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int kEsz = (DT == NESTI_F32) ? 4 : 2;
@@ -309,12 +326,17 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
   // ---- X8: f16 hi * W_hi per tap, FP8 cross terms per tap pair ---------------------------------------------------------------
   uint4 a8[2][2], b8[2][2];                              // a8: TWO rolling tile buffers (tiles j and j + 2 of a cross step share one) x
                                                          // [slot 2 (lo8), slot 3 (hi8)]; b8: [column tile][slot 2 (W_hi8), slot 3 (W_lo8)]
-  int sc_a = p.x8_scale_a, sc_b = p.x8_scale_b;          // E8M0 block scales (2^-sa, 2^-sb), one per operand and layer
-  asm volatile("" : "+v"(sc_a), "+v"(sc_b));             // the scale operands are VGPRs (hipcc fails to copy them out of SGPRs itself)
+  int sc_a = p.x8_scale_a, sc_b = p.x8_scale_b;          // X8: E8M0 block scales (2^-sa, 2^-sb), one per operand and layer
+  if constexpr (!X6) asm volatile("" : "+v"(sc_a), "+v"(sc_b));   // the scale operands are VGPRs (hipcc fails to copy them out of SGPRs itself)
   auto mma8 = [&](f32x16& c, const uint4 (&av)[2], const uint4 (&bv)[2]) __attribute__((always_inline)) {
     const i32x8n_t a_ = {(int)av[0].x, (int)av[0].y, (int)av[0].z, (int)av[0].w, (int)av[1].x, (int)av[1].y, (int)av[1].z, (int)av[1].w};
     const i32x8n_t b_ = {(int)bv[0].x, (int)bv[0].y, (int)bv[0].z, (int)bv[0].w, (int)bv[1].x, (int)bv[1].y, (int)bv[1].z, (int)bv[1].w};
-    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c, 0, 0, 0, sc_a, 0, sc_b);
+    if constexpr (X6) {    // e2m3: 32 six-bit elements in dwords 0-5, the block's own E8M0 scale in byte 0 of dword 6 (the instruction ignores
+                           // dwords 6-7 as data: scripts/fp6_probe.hip); an out-of-range or dead half reads zeros, scale 2^-127 included
+      c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c, 2, 2, 0, (int)av[1].z, 0, (int)bv[1].z);
+    } else {
+      c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a_, b_, c, 0, 0, 0, sc_a, 0, sc_b);
+    }
   };
   // A cross step (the tap that ends a pair) walks the four tiles with two FP8 fragment buffers: tiles 0 / 1 arrive prefetched, tile
   // j + 2's fragments of the SAME pair are read into tile j's buffer right behind tile j's MFMAs (tile j + 1's four MFMAs cover the
@@ -391,14 +413,14 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
           // tiles 2 / 3 of THIS pair behind tiles 0 / 1, tiles 0 / 1 of the NEXT pair behind tiles 2 / 3
           const unsigned src8 = j < 2 ? (xrow ? a8_x(j + 2) : cb8) + (j + 2) * kTileN : (next_x ? a8_x(j - 2) : nb8) + (j - 2) * kTileN;
           a8[j & 1][0] = lds128n(src8);
-          a8[j & 1][1] = lds128n(src8 + a8_d1);
+          a8[j & 1][1] = lds_hi16n<X6>(src8 + a8_d1);
         }
       }
       if (cross) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           b8[n][0] = lds128n(bsrc8 + n * kTileN);
-          b8[n][1] = lds128n(bsrc8 + b8_d1 + n * kTileN);
+          b8[n][1] = lds_hi16n<X6>(bsrc8 + b8_d1 + n * kTileN);
         }
       }
     }
@@ -425,14 +447,14 @@ __device__ __forceinline__ void conv8n_tile(const ConvParams& p, const unsigned 
         for (int n = 0; n < 2; ++n) {
           b[0][n][0] = lds128n(b_lane + n * kTileN);
           b8[n][0] = lds128n(b8k + n * kTileN);
-          b8[n][1] = lds128n(b8k + b8_d1 + n * kTileN);
+          b8[n][1] = lds_hi16n<X6>(b8k + b8_d1 + n * kTileN);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) a[j][0] = lds128n(nb0 + j * kTileN);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           a8[j][0] = lds128n(nb8 + j * kTileN);
-          a8[j][1] = lds128n(nb8 + a8_d1 + j * kTileN);
+          a8[j][1] = lds_hi16n<X6>(nb8 + a8_d1 + j * kTileN);
         }
       } else {
       load_b(b[1], b_lane);
@@ -604,6 +626,10 @@ int launch_conv8n_dt(const ConvParams& p, int k, hipStream_t stream) {
   if constexpr (DT == NESTI_F16) {
     if (p.x8) {
       if (!p.aux8_in || p.aux8_stride <= 0 || !p.split) NESTI_FAIL("launch_conv8n: the FP8 cross-term loop needs the side buffer of e4m3 planes and pair outputs");
+      if (p.x8_fmt == 6) {
+        if (k == 5) return launch_conv8n_one<DT, 5, 3>(p, stream);
+        if (k == 3) return launch_conv8n_one<DT, 3, 3>(p, stream);
+      }
       if (k == 5) return launch_conv8n_one<DT, 5, 2>(p, stream);
       if (k == 3) return launch_conv8n_one<DT, 3, 2>(p, stream);
     }

@@ -82,6 +82,12 @@ struct ConvParams {
   void* aux8_out;
   int aux8_stride;
   int x8, x8_sa, x8_sc, x8_scale_a, x8_scale_b;
+  // x8_fmt == 6: the block-scaled FP6 (e2m3) form of the same cross terms (conv8n.hip X6).  The side buffer keeps its geometry; the 32
+  // bytes of a row's 16-channel chunk (16 where lo8 went, 16 where hi8 went) now hold 32 six-bit elements -- slot 2i = e2m3(lo_i 2^11 / s),
+  // slot 2i + 1 = e2m3(hi_i / s) -- then the block's own scale s = 2^(E - 2), E = exponent of the chunk's largest |hi|, as an E8M0 byte
+  // (byte 24), zeros after it; |lo_i 2^11| <= |hi_i| element by element, so one scale serves both halves.  The weight rows follow the
+  // same pattern (model.hip: pack_layer_x6, the 2^-11 folded into their scale byte); x8_sa / x8_sc / x8_scale_* are not used.
+  int x8_fmt;
   float acc_scale;     // the accumulators are multiplied by this before the bias (1, or 2^-s when the layer's packed weights
                        // carry a 2^s scale: NESTI_F16X3 keeps the weight pairs in f16's normal range that way)
   int8_t tap[kMaxTaps][4];   // dz, dy, dx, -

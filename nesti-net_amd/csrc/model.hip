@@ -488,6 +488,10 @@ struct nesti_model {
   // it (include/nesti_hip.h: nesti_model_set_x8_layers)
   std::vector<nesti::PackedLayer> packed_x8;
   int x8_mask = 0;
+  // the same layers once more in the block-scaled FP6 form of the cross terms, and which of the two forms forward calls use (8 or 6;
+  // include/nesti_hip.h: nesti_model_set_x8_format)
+  std::vector<nesti::PackedLayer> packed_x6;
+  int x8_fmt = 6;
   // ... and their conditioning guard (pool.hip: x8_guard_*): outputs with |n| below max(x8_guard_thr, NESTI_X8_GUARD_WIDEN x largest
   // measured |dn| / theta) are re-evaluated in f16x3 proper; gstat = the device counters (include/nesti_hip.h: nesti_x8_guard_stats_t)
   float x8_guard_thr = NESTI_X8_GUARD_DEFAULT;
@@ -504,7 +508,7 @@ struct nesti_model {
   float tau = 0.25f;
   unsigned long long* cstat = nullptr;
   ~nesti_model() {
-    for (auto* v : {&packed, &packed_fast, &packed_mix, &packed_x8})
+    for (auto* v : {&packed, &packed_fast, &packed_mix, &packed_x8, &packed_x6})
       for (auto& p : *v) {
         if (p.wpk) (void)hipFree(p.wpk);
         if (p.bias) (void)hipFree(p.bias);
@@ -651,7 +655,27 @@ uint8_t host_f32_to_e4m3(float f) {
 // The FP8 cross-term packing of one k^3 tap layer at 8^3 (conv8n.hip X8; NESTI_F16X8 / NESTI_F16X8C): per (column pair, 16-channel
 // chunk, tap) 64 rows x 64 B = [W_hi f16 k0..15 | W_hi8 k0..15 | W_lo8 k0..15] of the SAME scaled weights the pair packing holds
 // (W 2^e, |W| 2^e < 2^14): W_hi8 = e4m3(W_hi 2^sb), W_lo8 = e4m3((W - W_hi) 2^(sb + 11)) with sb = -6 (both below 256).
-int pack_layer_x8(const LayerDesc& d, const TensorTable& tt, PackedLayer* pl) {
+// e2m3 (1-2-3, bias 1, largest finite 7.5) code of a non-negative magnitude already divided by its block scale: round to nearest even,
+// saturating.  The code is monotone in the value and the grid is piecewise uniform: [0, 1) step 1/8 (subnormals), [1, 2) 1/8, [2, 4) 1/4,
+// [4, 7.5] 1/2; a value that rounds up to the next binade's first point gets that point's code.
+uint8_t host_mag_to_e2m3(float a) {
+  if (!(a == a)) return 31;
+  int code;
+  if (a < 2.f) code = (int)nearbyintf(a * 8.f);                    // 0 .. 16 (16 = 2.0)
+  else if (a < 4.f) code = 16 + (int)nearbyintf((a - 2.f) * 4.f);    // .. 24 (= 4.0)
+  else code = 24 + (int)nearbyintf((std::min(a, 8.f) - 4.f) * 2.f);
+  return (uint8_t)std::min(code, 31);
+}
+inline uint8_t host_f32_to_e2m3(float f, float inv_scale) {
+  return (uint8_t)(host_mag_to_e2m3(fabsf(f) * inv_scale) | (std::signbit(f) ? 32 : 0));
+}
+
+// fmt == 6: the block-scaled FP6 form of the same rows (conv8n.hip X6; kernels.h: ConvParams::x8_fmt): the 32 bytes that hold
+// [W_hi8 | W_lo8] hold instead 32 e2m3 elements -- slot 2i = W_hi[i] / s, slot 2i + 1 = W_lo[i] 2^11 / s of the chunk's 16 input channels
+// (the order the producer's conversion instruction writes [lo | hi] activations in, so that slot products are lo W_hi and hi W_lo) -- and
+// in byte 24 the E8M0 code of s 2^-11 (s = 2^(E - 2), E = exponent of the chunk's largest |W_hi|; the 2^-11 undoes BOTH 2^11 pre-scales,
+// the activations' and the weights', since every product carries exactly one of them).
+int pack_layer_x8(const LayerDesc& d, const TensorTable& tt, PackedLayer* pl, int fmt = 8) {
   if (!use_conv8(d) || !d.scope2.empty()) NESTI_FAIL("internal: pack_layer_x8 is for the k^3 tap layers at 8^3");
   Folded f;
   if (fold_layer(d, d.scope, tt, &f)) return 1;
@@ -696,6 +720,7 @@ int pack_layer_x8(const LayerDesc& d, const TensorTable& tt, PackedLayer* pl) {
       for (int t = 0; t < pl->n_taps; ++t) {
         unsigned char* tile = host.data() + (((size_t)nt * pl->n_chunks + ch) * pl->n_taps + t) * tile_bytes;
         const float* wt = f.w + (size_t)tap_widx[t] * d.cin * d.cout;
+        float whi[16][64] = {}, wlo[16][64] = {};          // fmt 6: the chunk's pair split, per column
         for (int kc = 0; kc < chunk_ch; ++kc) {
           const int cr = inv[ch * chunk_ch + kc];
           if (cr < 0) continue;
@@ -709,10 +734,38 @@ int pack_layer_x8(const LayerDesc& d, const TensorTable& tt, PackedLayer* pl) {
             const int key = (nl >> 2) & 3;               // conv8n_kernel's weight-row swizzle
             unsigned char* row = tile + (size_t)nl * 64;
             memcpy(row + (((kc >> 3) ^ key) << 4) + (kc & 7) * 2, &h, 2);
+            if (fmt == 6) { whi[kc][nl] = hf; wlo[kc][nl] = (v - hf) * 2048.f; continue; }
             row[((2 ^ key) << 4) + kc] = host_f32_to_e4m3(hf * mul_hi8);
             row[((3 ^ key) << 4) + kc] = host_f32_to_e4m3((v - hf) * mul_lo8);
           }
         }
+        if (fmt == 6)
+          for (int nl = 0; nl < 64; ++nl) {
+            float amax = 0.f;
+            for (int kc = 0; kc < chunk_ch; ++kc) amax = std::max(amax, fabsf(whi[kc][nl]));
+            if (!(amax > 0.f) || !std::isfinite(amax)) continue;          // an all-zero (padding) block: codes 0, scale byte 0
+            int e;
+            (void)frexpf(amax, &e);                                        // amax = m 2^e, m in [0.5, 1): leading exponent e - 1
+            const int sexp = e - 1 - 2;                                    // s = 2^sexp: the largest element lands in [4, 8)
+            const float inv_s = ldexpf(1.f, -sexp);
+            unsigned char blk[32] = {};
+            for (int kc = 0; kc < chunk_ch; ++kc) {
+              const unsigned c2[2] = {host_f32_to_e2m3(whi[kc][nl], inv_s), host_f32_to_e2m3(wlo[kc][nl], inv_s)};
+              for (int j = 0; j < 2; ++j) {
+                const int pos = 6 * (2 * kc + j);
+                const unsigned w = c2[j] << (pos & 7);
+                blk[pos >> 3] |= (unsigned char)w;
+                blk[(pos >> 3) + 1] |= (unsigned char)(w >> 8);
+              }
+            }
+            const int sbyte = sexp - 11 + 127;
+            if (sbyte < 1 || sbyte > 254) NESTI_FAIL("internal: FP6 weight block scale out of the E8M0 range");
+            blk[24] = (unsigned char)sbyte;
+            const int key = (nl >> 2) & 3;
+            unsigned char* row = tile + (size_t)nl * 64;
+            memcpy(row + ((2 ^ key) << 4), blk, 16);
+            memcpy(row + ((3 ^ key) << 4), blk + 16, 16);
+          }
       }
   std::vector<float> bias_p((size_t)pl->n_tiles * 64, 0.f);
   for (int n = 0; n < d.cout; ++n) bias_p[n] = f.bias[n];
@@ -986,8 +1039,9 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
       const bool x2l = rc.fast && rc.m->packed_fast[op.layer].wpk == nullptr;
       const bool x8l = !rc.fast && !mixl && op.aux_in_buf >= 0 && op.x8_bit >= 0 && ((rc.x8 >> op.x8_bit) & 1) &&
                        op.layer < (int)rc.m->packed_x8.size() && rc.m->packed_x8[op.layer].wpk;
+      const bool x6 = rc.m->x8_fmt == 6;
       const PackedLayer& pl = x2l ? rc.m->packed[op.layer] : rc.fast ? rc.m->packed_fast[op.layer]
-                              : mixl ? rc.m->packed_mix[op.layer] : x8l ? rc.m->packed_x8[op.layer] : rc.m->packed[op.layer];
+                              : mixl ? rc.m->packed_mix[op.layer] : x8l ? (x6 ? rc.m->packed_x6 : rc.m->packed_x8)[op.layer] : rc.m->packed[op.layer];
       ConvParams p;
       memset(&p, 0, sizeof(p));
       p.in_pair = mixl ? 1 : 0;
@@ -1015,10 +1069,12 @@ int run_tower(const RunCtx& rc, const Tower& T, const void* X0, unsigned char* w
         const int sc = rc.m->packed[op.aux_layer].x8_sc;
         p.x8 = 1; p.aux8_in = ptr[op.aux_in_buf]; p.aux8_stride = T.bufs[op.aux_in_buf].C * 2;
         p.x8_scale_a = 127 - (sc + 11); p.x8_scale_b = 127 - pl.x8_sb;
+        p.x8_fmt = x6 ? 6 : 8;
       }
       if (!rc.fast && op.aux_out_buf >= 0 && (rc.x8 & op.x8_bits) && !rc.m->packed_x8.empty()) {   // producer
         p.aux8_out = ptr[op.aux_out_buf]; p.aux8_stride = T.bufs[op.aux_out_buf].C * 2;
         p.x8_sc = rc.m->packed[op.layer].x8_sc; p.x8_sa = p.x8_sc + 11;
+        p.x8_fmt = x6 ? 6 : 8;
       }
       memcpy(p.tap, pl.tap, sizeof(p.tap));
       p.remap = conv_remap(d.k, d.log2S, pl.n_taps);
@@ -1389,11 +1445,13 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
   if (x8) {
     // the experts' tap layers at 8^3 once more in the FP8 cross-term packing, and the pre-scale of the planes their block's conv1 writes
     m->packed_x8.resize(m->graph.layers.size());
+    m->packed_x6.resize(m->graph.layers.size());
     for (const Tower& T : m->graph.experts)
       for (const Op& op : T.ops) {
         if (op.kind != Op::CONV) continue;
         if (op.aux_out_buf >= 0) m->packed[op.layer].x8_sc = x8_activation_exponent(m->graph.layers[op.layer], tt);
         if (op.aux_in_buf >= 0 && pack_layer_x8(m->graph.layers[op.layer], tt, &m->packed_x8[op.layer])) return 1;
+        if (op.aux_in_buf >= 0 && pack_layer_x8(m->graph.layers[op.layer], tt, &m->packed_x6[op.layer], 6)) return 1;
       }
     m->x8_mask = 0xF;          // all four tap layers at 8^3 (include/nesti_hip.h: nesti_model_set_x8_layers)
     NESTI_CHECK_HIP(hipMalloc((void**)&m->gstat, 64));
@@ -1446,6 +1504,14 @@ int nesti_model_set_x8_layers(nesti_model_t* m, int mask) {
   if (m->packed_x8.empty()) NESTI_FAIL("nesti_model_set_x8_layers: not an NESTI_F16X8 / NESTI_F16X8C model");
   if (mask < 0 || mask > 0xF) NESTI_FAIL("nesti_model_set_x8_layers: mask has four bits (inception1 conv2 / conv3, inception2 conv2 / conv3)");
   m->x8_mask = mask;
+  return 0;
+}
+
+int nesti_model_set_x8_format(nesti_model_t* m, int bits) {
+  if (!m) NESTI_FAIL("nesti_model_set_x8_format: null model");
+  if (m->packed_x8.empty()) NESTI_FAIL("nesti_model_set_x8_format: not an NESTI_F16X8 / NESTI_F16X8C model");
+  if (bits != 8 && bits != 6) NESTI_FAIL("nesti_model_set_x8_format: 8 (e4m3, one scale per layer) or 6 (e2m3, one scale per 16-channel block)");
+  m->x8_fmt = bits;
   return 0;
 }
 

@@ -135,6 +135,11 @@ class NestiNet:
         bit 0 / 1 = inception1 conv2 / conv3, bit 2 / 3 = inception2 conv2 / conv3; default 0b1111; 0 = f16x3 proper)."""
         _lib.check(self.lib.nesti_model_set_x8_layers(self._handle, int(mask)), "nesti_model_set_x8_layers")
 
+    def set_x8_format(self, bits):
+        """dtype 'f16x8' / 'f16x8c': 8 = e4m3 cross terms with one scale per layer, 6 = block-scaled e2m3 (FP6: twice the FP8 matrix rate,
+        ~1.2x the residual; ``nesti_model_set_x8_format``).  Recalibrate the conditioning guard afterwards."""
+        _lib.check(self.lib.nesti_model_set_x8_format(self._handle, int(bits)), "nesti_model_set_x8_format")
+
     def set_x8_guard(self, thr):
         """dtype 'f16x8' / 'f16x8c': the conditioning guard's threshold on |n| (``nesti_model_set_x8_guard``): an expert output of
         smaller norm is re-evaluated in f16x3 proper.  ``thr < 0`` switches the guard off, ``float('inf')`` re-evaluates every query

@@ -52,7 +52,13 @@ VARIANTS = [
     ("e4m3 all taps", "e4m3", [I1C2, I1C3, I2C2, I2C3, I4C2, I4C3, I6C2, I6C3]),
     ("e4m3 all taps, lo only", "e4m3_lo", [I1C2, I1C3, I2C2, I2C3, I4C2, I4C3, I6C2, I6C3]),   # hi*W_lo stays f16: which cross term carries the error?
     ("e2m3 blocks all taps at 8^3", "e2m3", [I1C2, I1C3, I2C2, I2C3]),
+    # the form the instruction can actually run on this kernel's rows: a lane's K block is one tap's [lo 16 ch | hi 16 ch] with ONE scale,
+    # taken from max |hi| of the 16 channels (|lo 2^11| <= |hi| element by element), weights likewise per (tap, 16 ch, column)
+    ("e2m3 shared-scale all taps at 8^3", "e2m3s", [I1C2, I1C3, I2C2, I2C3]),
+    ("e2m3 shared-scale both 5^3", "e2m3s", [I1C3, I2C3]),
 ]
+if os.environ.get("FP8X_VARIANTS"):
+    VARIANTS = [v for v in VARIANTS if any(t in v[0] for t in os.environ["FP8X_VARIANTS"].split(","))]
 
 
 def q_e4m3(x):
@@ -76,6 +82,29 @@ def q_e2m3_blocks(x, block=16):
     qv = (torch.round(m / step) * step).clamp(max=7.5) * torch.sign(v) * s
     qv = qv.reshape(shp[:-1] + (shp[-1] + pad,))
     return qv[..., :shp[-1]].contiguous() if pad else qv
+
+
+def e2m3_round(m):
+    """Magnitudes (already divided by the block scale) to the e2m3 grid {0, .125 .. 7.5}, saturating."""
+    be = torch.floor(torch.log2(m.clamp_min(1e-30))).clamp(0, 2)
+    step = torch.exp2(be - 3)
+    return (torch.round(m / step) * step).clamp(max=7.5)
+
+
+def q_e2m3_shared(hi, lo, block=16):
+    """[hi | lo 2^11] of `block` channels under ONE power-of-two scale 2^(E - 2), E = exponent of the block's largest |hi| (so the largest
+    element lands in [4, 8) and saturates at 7.5).  Returns the dequantised (hi6, lo6) in true units."""
+    shp = hi.shape
+    pad = (-shp[-1]) % block
+    if pad:
+        hi, lo = torch.nn.functional.pad(hi, (0, pad)), torch.nn.functional.pad(lo, (0, pad))
+    h, l = hi.reshape(-1, block), lo.reshape(-1, block) * 2048.0
+    amax = h.abs().amax(dim=1, keepdim=True)
+    s = torch.exp2(torch.floor(torch.log2(amax.clamp_min(1e-30))) - 2)
+    hq = e2m3_round(h.abs() / s) * torch.sign(h) * s
+    lq = e2m3_round(l.abs() / s) * torch.sign(l) * s / 2048.0
+    hq, lq = hq.reshape(shp[:-1] + (shp[-1] + pad,)), lq.reshape(shp[:-1] + (shp[-1] + pad,))
+    return (hq[..., :shp[-1]].contiguous(), lq[..., :shp[-1]].contiguous()) if pad else (hq, lq)
 
 
 def split16(x):
@@ -114,6 +143,8 @@ class Layer:
         # FP6: blocks of 16 input channels per (tap, output column)
         self.w_hi6 = q_e2m3_blocks(self.w_hi.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
         self.w_lo6 = q_e2m3_blocks(self.w_lo.transpose(1, 2).contiguous()).transpose(1, 2).contiguous()
+        h6, l6 = q_e2m3_shared(self.w_hi.transpose(1, 2).contiguous(), self.w_lo.transpose(1, 2).contiguous())
+        self.w_hi6s, self.w_lo6s = h6.transpose(1, 2).contiguous(), l6.transpose(1, 2).contiguous()
         self.bias = torch.as_tensor(b.astype(np.float32), device=dev)
         self.relu = relu
         self.scope = scope
@@ -169,6 +200,9 @@ def run_layer(L, x, mode, calibrate=False):
                 acc = acc + taps_matmul(hi, L.w_lo, k)
         elif mode == "e2m3":
             acc = acc + taps_matmul(q_e2m3_blocks(lo), L.w_hi6, k) + taps_matmul(q_e2m3_blocks(hi), L.w_lo6, k)
+        elif mode == "e2m3s":
+            h6, l6 = q_e2m3_shared(hi, lo)
+            acc = acc + taps_matmul(l6, L.w_hi6s, k) + taps_matmul(h6, L.w_lo6s, k)
         else:
             raise ValueError(mode)
     y = acc * L.acc_scale + L.bias

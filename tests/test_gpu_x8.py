@@ -23,7 +23,10 @@ def _omc(a, b):
     return 1.0 - (a * b).sum(1) / np.maximum(np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1), 1e-300)
 
 
-def test_x8_experts_pinned_to_f16x3(gpu_device):
+@pytest.mark.parametrize("fmt", [6, 8])
+def test_x8_experts_pinned_to_f16x3(gpu_device, fmt):
+    """fmt 6 (the default): the cross terms as block-scaled FP6 e2m3 (one scale per 16-channel block of a row, conv8n.hip X6); fmt 8: FP8
+    e4m3 with one scale per layer (X8).  Same assertions for both; the FP6 residual is ~1.15x the FP8 one."""
     import nesti_net_amd  # noqa: F401
     from nesti_net_amd import parity, synth, weights
     from nesti_net_amd.calibrate import calibrate_gate, calibrate_gate_margin
@@ -39,6 +42,8 @@ def test_x8_experts_pinned_to_f16x3(gpu_device):
     W = calibrate_gate(cfg, weights.synthetic_weights(cfg), p_d[:512], n_d[:512], device=gpu_device)
     n3, e3, p3 = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=Q)(p_d, n_d)
     net8 = NestiNet(cfg, W, dtype="f16x8", device=gpu_device, max_batch=Q)
+    net8.set_x8_format(fmt)
+    net8.set_x8_guard(-1.0)          # the bare loop: every row carries the 6 / 8-bit cross terms (the guard has its own test below)
     n8, e8, p8 = net8(p_d, n_d)
     torch.cuda.synchronize()
     n3, e3, n8, e8 = n3.cpu().numpy(), e3.cpu().numpy(), n8.cpu().numpy(), e8.cpu().numpy()
@@ -46,7 +51,7 @@ def test_x8_experts_pinned_to_f16x3(gpu_device):
     assert len(np.unique(e3)) == cfg.n_experts
     omc = _omc(n8, n3)
     dn = np.linalg.norm(n8.astype(np.float64) - n3, axis=1)
-    print("f16x8 vs f16x3 on %d queries: 1-cos p50 %.3g p99 %.3g max %.3g, |dn| p50 %.3g max %.3g, routing %s"
+    print("format %d:" % fmt, "f16x8 vs f16x3 on %d queries: 1-cos p50 %.3g p99 %.3g max %.3g, |dn| p50 %.3g max %.3g, routing %s"
           % (Q, np.quantile(omc, .5), np.quantile(omc, .99), omc.max(), np.quantile(dn, .5), dn.max(), np.bincount(e3).tolist()))
     assert omc.max() <= 2.5e-6
     assert dn.max() > 0            # the FP8 loop really ran (mask 0 below is the bit-identical case)
@@ -73,6 +78,8 @@ def test_x8_experts_pinned_to_f16x3(gpu_device):
     del net8
     # the cascade on top: f16x8c == f16x8 once the margin is calibrated
     net_c = NestiNet(cfg, W, dtype="f16x8c", device=gpu_device, max_batch=Q)
+    net_c.set_x8_format(fmt)
+    net_c.set_x8_guard(-1.0)
     tau = calibrate_gate_margin(net_c, p_d[:2048], n_d[:2048])
     nc, ec, _ = net_c(p_d, n_d)
     st = net_c.cascade_stats()
@@ -81,6 +88,10 @@ def test_x8_experts_pinned_to_f16x3(gpu_device):
     assert np.array_equal(ec.cpu().numpy(), e8) and np.array_equal(nc.cpu().numpy(), n8)
     with pytest.raises(Exception):
         NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=8).set_x8_layers(0xA)
+    with pytest.raises(Exception):
+        NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=8).set_x8_format(6)
+    with pytest.raises(Exception):
+        net_c.set_x8_format(4)
 
 
 def test_x8_prescale_follows_the_batch_norm_and_saturates_gracefully(gpu_device):
@@ -102,8 +113,10 @@ def test_x8_prescale_follows_the_batch_norm_and_saturates_gracefully(gpu_device)
     W0 = weights.synthetic_weights(cfg)
     expert = torch.full((len(q),), 3, dtype=torch.int32, device=gpu_device)       # one expert: Expert_3
 
-    def run(W, dtype):
+    def run(W, dtype, fmt=8):
         net = NestiNet(cfg, W, dtype=dtype, device=gpu_device, max_batch=len(q))
+        if dtype == "f16x8":
+            net.set_x8_format(fmt)           # the pre-scale belongs to the e4m3 form; the FP6 form scales every block by itself (below)
         return net.experts(net.mups(p_d, n_d), expert).cpu().numpy()
 
     Wa = dict(W0)
@@ -122,6 +135,10 @@ def test_x8_prescale_follows_the_batch_norm_and_saturates_gracefully(gpu_device)
     ob = _omc(n8, n3)
     print("batch-norm variance 1000x too small (saturating planes): 1-cos p50 %.3g max %.3g" % (np.quantile(ob, .5), ob.max()))
     assert np.all(np.isfinite(n8)) and ob.max() <= 5e-3
+    # the FP6 form carries one scale per 16-channel block, taken from the data: neither case can push it out of range
+    o6a, o6b = _omc(run(Wa, "f16x8", 6), run(Wa, "f16x3")), _omc(run(Wb, "f16x8", 6), n3)
+    print("FP6 form: 16x larger activations 1-cos max %.3g, lying batch-norm 1-cos max %.3g" % (o6a.max(), o6b.max()))
+    assert o6a.max() <= 2.5e-6 and o6b.max() <= 2.5e-6
 
 
 def test_x8_conditioning_guard(gpu_device):
