@@ -10,11 +10,11 @@ second leg times ONE cloud's rows sharded over the N ranks (the north star's "po
 strong scaling) and prints it as "strong" in the same line.
 
 The headline dtype is f16x8c (round 6): every output is computed in f16 hi + lo pairs -- three MFMA products per multiply,
-f16x3 -- except that the experts' tap layers at 8^3 compute their two CROSS terms (2^-11 of the result) with one FP8 MFMA
-(NESTI_F16X8C, include/nesti_hip.h), and the gating net additionally runs in plain f16 first as a filter (NESTI_F16X3C) --
+f16x3 -- except that the experts' tap layers at 8^3 compute their two CROSS terms (2^-11 of the result) with one block-scaled FP6
+MFMA (NESTI_F16X8C, nesti_model_set_x8_format: include/nesti_hip.h), and the gating net additionally runs in plain f16 first as a filter (NESTI_F16X3C) --
 a mode that meets the north star's parity clause (see "parity": every arg-max difference and the 1 - cos distribution against
 the exact-fp32 mode over the whole timed cloud; "pair_cascade_mode" is last round's headline f16x3c on the same box, "x8_guard" the
-conditioning guard's counters, "x8_k5_only_mode" the same with only the 5^3 layers in the FP8 form).  The plain 16-bit mode ("fast_mode", f16) is faster still and does NOT meet it.
+conditioning guard's counters, "x8_e4m3_mode" the same with the cross terms in FP8 e4m3 instead of the default block-scaled FP6).  The plain 16-bit mode ("fast_mode", f16) is faster still and does NOT meet it.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \

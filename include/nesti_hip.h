@@ -53,7 +53,8 @@ enum { NESTI_F32 = 0, NESTI_BF16 = 1, NESTI_F16 = 2, NESTI_BF16X3 = 3, NESTI_F16
 /* NESTI_F16X8 / NESTI_F16X8C (round 6; MODEL dtypes only, experts_n_est on the 8^3 grid): NESTI_F16X3 / NESTI_F16X3C with the two
  * CROSS terms of the pair scheme -- lo * W_hi + hi * W_lo, 2^-11 of a layer's result -- of the EXPERT towers' tap layers at 8^3
  * (models/experts_n_est.py:258-262: conv2 (3^3) and conv3 (5^3) of inception1 / inception2, 86 % of an expert's multiply-accumulates)
- * computed by one block-scaled FP8 MFMA (e4m3 x e4m3, K = 64, fp32 accumulate into the same accumulator) instead of four f16 MFMAs;
+ * computed by one block-scaled MFMA of a narrow format (K = 64, fp32 accumulate into the same accumulator: FP6 e2m3 x e2m3 with one scale
+ * per 16-channel block by default, or FP8 e4m3 x e4m3 with one scale per layer -- nesti_model_set_x8_format) instead of four f16 MFMAs;
  * hi * W_hi stays an exact f16 product.  The gating net -- filter AND recheck -- is untouched, so expert_out is NESTI_F16X3C's bit for
  * bit.  The normals differ from NESTI_F16X3's by a residual 28x below single-product f16 (1 - cos p50 6e-10, p99 2e-8), and the
  * queries on which that residual could matter -- expert outputs of very small norm -- are evaluated again in f16x3 proper by the
