@@ -295,6 +295,29 @@ def moe_forward(mups, W, expert_dict=None, dtype=torch.float64, top1_only=False)
 # ---------------------------------------------------------------------------
 # naive loop implementations used ONLY to pin the semantics above (tiny sizes)
 # ---------------------------------------------------------------------------
+def over_chunks(fn, n_rows, chunk=16, workers=None, threads=4):
+    """``[fn(slice) for consecutive slices of `chunk` rows]`` with the slices spread over a few Python threads, each torch call on
+    ``threads`` intra-op threads.  Test plumbing, not arithmetic: torch's fp64 conv3d on the CPU gets SLOWER beyond ~16 threads
+    (measured on a 256-core host: 128 queries in 19 s on 16 threads, 25 s on 32, 37 s on 64), while independent chunks scale; the GIL is
+    released inside the operators.  Results may differ from a single-chunk run in the last bits of an fp64 (BLAS blocking), nothing a
+    tolerance of these tests can see."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    spans = [slice(i, min(n_rows, i + chunk)) for i in range(0, n_rows, chunk)]
+    if workers is None:
+        workers = max(1, min(16, (os.cpu_count() or 1) // threads))
+    workers = min(workers, len(spans))
+    if workers <= 1:
+        return [fn(sp) for sp in spans]
+    before = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        with ThreadPoolExecutor(workers) as ex:
+            return list(ex.map(fn, spans))
+    finally:
+        torch.set_num_threads(before)
+
+
 def naive_conv3d_same(x, w, b):
     x, w = np.asarray(x, np.float64), np.asarray(w, np.float64)
     B, D, H, Wd, C = x.shape

@@ -49,7 +49,7 @@ def test_reference_artefacts_to_normals(tmp_path, gpu_device):
     assert np.array_equal(p_d[:64].cpu().numpy().view(np.uint32), o_pts.view(np.uint32))
     mups_o = mups_ref.mups_assemble(o_pts, o_neff, cfg2.n_scales)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    ref = [net_ref.moe_forward(mups_o[i:i + 32], W2, expert_dict=cfg2.expert_dict, dtype=torch.float64, top1_only=True) for i in (0, 32)]
+    ref = net_ref.over_chunks(lambda sl: net_ref.moe_forward(mups_o[sl], W2, expert_dict=cfg2.expert_dict, dtype=torch.float64, top1_only=True), 64)
     ref = {k: torch.cat([r[k] for r in ref]).numpy() for k in ("probs", "expert", "normals")}
     n32, e32, p32 = NestiNet(cfg2, W2, dtype="f32", device=gpu_device, max_batch=64)(p_d[:64], n_d[:64])
     torch.cuda.synchronize()

@@ -39,12 +39,11 @@ def _fixture_config(g):
     return cfg
 
 
-def _oracle_moe(mups, W, cfg, chunk=64):
-    """oracle.net_ref.moe_forward in chunks (bounds host memory); fp64."""
+def _oracle_moe(mups, W, cfg):
+    """oracle.net_ref.moe_forward in chunks of 16 queries spread over host threads (net_ref.over_chunks); fp64."""
     from oracle import net_ref
-    torch.set_num_threads(min(32, os.cpu_count() or 1))      # torch-CPU conv3d regresses well before 256 threads
-    outs = [net_ref.moe_forward(mups[i:i + chunk], W, expert_dict=cfg.expert_dict, dtype=torch.float64, top1_only=True)
-            for i in range(0, len(mups), chunk)]
+    outs = net_ref.over_chunks(lambda sl: net_ref.moe_forward(mups[sl], W, expert_dict=cfg.expert_dict, dtype=torch.float64, top1_only=True),
+                               len(mups))
     return {k: torch.cat([o[k] for o in outs]).numpy() for k in ("probs", "expert", "normals")}
 
 
@@ -84,7 +83,7 @@ def test_f32_path_matches_oracle_across_fixture_cloud(name, gpu_device):
     normals, expert, probs = net(p_d, n_d)
     torch.cuda.synchronize()
     if cfg.arch == ARCH_SINGLE:
-        ref = torch.cat([net_ref.single_forward(mups_o[i:i + 64], W, dtype=torch.float64) for i in range(0, len(q), 64)]).numpy()
+        ref = torch.cat(net_ref.over_chunks(lambda sl: net_ref.single_forward(mups_o[sl], W, dtype=torch.float64), len(q))).numpy()
         c = _cos(normals.cpu().numpy(), ref)
         n3, _, _ = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=len(q))(p_d, n_d)
         c3 = _cos(n3.cpu().numpy(), ref)

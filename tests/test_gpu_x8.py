@@ -68,6 +68,8 @@ def test_x8_experts_pinned_to_f16x3(gpu_device, fmt):
     omc_f = _omc(nf.cpu().numpy(), n3)
     print("mask 0xA (5^3 layers only): 1-cos p99 %.3g max %.3g" % (np.quantile(omc_f, .99), omc_f.max()))
     assert omc_f.max() <= 2.5e-6
+    if fmt == 8:          # the per-layer and cascade checks below run once, in the default form
+        return
     # one layer at a time: each bit alone moves the result, and stays inside the bound
     for bit in range(4):
         net8.set_x8_layers(1 << bit)
@@ -113,30 +115,38 @@ def test_x8_prescale_follows_the_batch_norm_and_saturates_gracefully(gpu_device)
     W0 = weights.synthetic_weights(cfg)
     expert = torch.full((len(q),), 3, dtype=torch.int32, device=gpu_device)       # one expert: Expert_3
 
-    def run(W, dtype, fmt=8):
-        net = NestiNet(cfg, W, dtype=dtype, device=gpu_device, max_batch=len(q))
-        if dtype == "f16x8":
-            net.set_x8_format(fmt)           # the pre-scale belongs to the e4m3 form; the FP6 form scales every block by itself (below)
-        return net.experts(net.mups(p_d, n_d), expert).cpu().numpy()
+    def run(W):
+        """-> the experts' normals in f16x3, in the e4m3 form (whose pre-scale this test is about) and in the FP6 form (which scales every
+        block by itself)."""
+        net3 = NestiNet(cfg, W, dtype="f16x3", device=gpu_device, max_batch=len(q))
+        o3 = net3.experts(net3.mups(p_d, n_d), expert).cpu().numpy()
+        del net3
+        net = NestiNet(cfg, W, dtype="f16x8", device=gpu_device, max_batch=len(q))
+        m = net.mups(p_d, n_d)
+        net.set_x8_format(8)
+        o8 = net.experts(m, expert).cpu().numpy()
+        net.set_x8_format(6)
+        return o3, o8, net.experts(m, expert).cpu().numpy()
 
     Wa = dict(W0)
     for blk in ("inception1", "inception2"):
         k = blk + "Expert_3_conv1/bn/"
         Wa[k + "gamma"] = (W0[k + "gamma"] * 16).astype(np.float32)
         Wa[k + "beta"] = (W0[k + "beta"] * 16).astype(np.float32)
-    oa = _omc(run(Wa, "f16x8"), run(Wa, "f16x3"))
+    a3, a8, a6 = run(Wa)
+    oa = _omc(a8, a3)
     print("16x larger conv1 activations: 1-cos max %.3g" % oa.max())
     assert oa.max() <= 2.5e-6
     Wb = dict(W0)
     for blk in ("inception1", "inception2"):
         k = blk + "Expert_3_conv1/bn/"
         Wb[k + "var"] = (W0[k + "var"] / 1000).astype(np.float32)
-    n8, n3 = run(Wb, "f16x8"), run(Wb, "f16x3")
+    n3, n8, b6 = run(Wb)
     ob = _omc(n8, n3)
     print("batch-norm variance 1000x too small (saturating planes): 1-cos p50 %.3g max %.3g" % (np.quantile(ob, .5), ob.max()))
     assert np.all(np.isfinite(n8)) and ob.max() <= 5e-3
     # the FP6 form carries one scale per 16-channel block, taken from the data: neither case can push it out of range
-    o6a, o6b = _omc(run(Wa, "f16x8", 6), run(Wa, "f16x3")), _omc(run(Wb, "f16x8", 6), n3)
+    o6a, o6b = _omc(a6, a3), _omc(b6, n3)
     print("FP6 form: 16x larger activations 1-cos max %.3g, lying batch-norm 1-cos max %.3g" % (o6a.max(), o6b.max()))
     assert o6a.max() <= 2.5e-6 and o6b.max() <= 2.5e-6
 
