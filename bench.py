@@ -362,7 +362,7 @@ def roofline(run, dtype, cfg, clouds_np, world, frac, calibrated):
     # scripts/summarize_pmc.py).  Counters cannot be read from inside the process, so the figure is quoted from
     # the profile only when dtype, batch and routing match; otherwise null.
     traffic, src = None, None
-    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_fp6_pmc_traffic.json", "r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         pmc_file = os.path.join(REPO, "profiles", name)
         if traffic is None and os.path.exists(pmc_file):
             pj = json.load(open(pmc_file))

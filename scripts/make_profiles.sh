@@ -26,7 +26,7 @@ done
 python3 $R/scripts/summarize_pmc.py /tmp/pmc 100000 $O/pmc_traffic.json f16x8c 100000
 (echo "== f16x3c with tau = 0: the cascade's FILTER pass as the product runs it (plain-f16 tap layers, X2 loop conv_igemm_kernel<..., true> in the one-tap layers), batch 8192"; PROF_ROWS=24 bash $R/scripts/pmc_gate.sh 8192 "" f16x3c
  echo "== f16x3: the gate's RECHECK pass (pair K loop), batch 4096"; PROF_ROWS=24 bash $R/scripts/pmc_gate.sh 4096 "" f16x3
- echo "== expert towers, f16x8 (the 5^3 tap layers in the FP8 cross-term loop conv8n_kernel<2, 5, 2, .>), 4096 queries: half Expert_0, half Expert_6"; PROF_DRIVER=prof_expert.py PROF_ROWS=40 bash $R/scripts/pmc_gate.sh 4096 "" f16x8
+ echo "== expert towers, f16x8 (the 5^3 tap layers in the FP8 cross-term loop conv8n_kernel<2, 5, 3, .> since the FP6 form is the default), 4096 queries: half Expert_0, half Expert_6"; PROF_DRIVER=prof_expert.py PROF_ROWS=40 bash $R/scripts/pmc_gate.sh 4096 "" f16x8
  echo "== expert towers, f16x3 (pair K loop everywhere), the same queries"; PROF_DRIVER=prof_expert.py PROF_ROWS=40 bash $R/scripts/pmc_gate.sh 4096 "" f16x3) > $O/pmc_mfma.txt 2>&1
 bash $R/scripts/per_launch_trace.sh f16x8c > /dev/null 2>&1; cp $R/gpurun_out/per_launch_f16x8c.txt $O/ 2>/dev/null
 head -c 400 $O/bench_n1.json; echo; head -6 $O/bench_kernel_stats.csv; tail -3 $O/pmc_mfma.txt | cut -c1-200

@@ -34,7 +34,7 @@ def klass(k):
     """conv launches by kernel class and K loop: conv8 5^3 / 3^3, taps (igemm, several taps), 1x1 + FC (igemm, one tap)."""
     m = re.search(r"conv8n_kernel<(\d), (\d), (\d|true|false)", k)        # third argument: 0 plain, 1 the pair K loop, 2 the FP8 cross-term loop
     if m:
-        return "conv8_k%s%s" % (m.group(2), {"true": "_pair", "1": "_pair", "2": "_x8"}.get(m.group(3), ""))
+        return "conv8_k%s%s" % (m.group(2), {"true": "_pair", "1": "_pair", "2": "_x8", "3": "_x8"}.get(m.group(3), ""))
     m = re.search(r"conv4n_kernel<(\d), (\d), (true|false)", k)
     if m:
         return "taps_4_2" + ("_pair" if m.group(3) == "true" else "")
