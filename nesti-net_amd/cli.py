@@ -37,7 +37,7 @@ def build_parser():
                    help="MFMA precision mode.  auto (default): the modes that keep .normals and .experts within the reference's "
                         "tolerance (arg-max exact up to fp32 ties, 1e-5 cosine) -- f16x8c for experts_n_est on the 8^3 grid (f16 hi + lo "
                         "pairs behind the two-stage gate, whose margin is calibrated on every shape and widens itself when the measured "
-                        "error approaches it; the experts' tap layers at 8^3 take their two cross terms through one FP8 MFMA and outputs of "
+                        "error approaches it; the experts' tap layers at 8^3 take their two cross terms through one block-scaled FP6 MFMA and outputs of "
                         "small norm are evaluated again in f16x3: .experts equal f16x3c's, .normals stay within ~1e-6 cosine of f16x3's), f16x3c on the 3^3 grid, f16x3 for the other "
                         "models.  NOTE: with f16x3c / f16x8c the .experts_probs rows of queries "
                         "the filter pass decided alone (~90 %%) are that pass's probabilities, within ~0.013 of the fp32 values; "
@@ -47,7 +47,7 @@ def build_parser():
                    help="dtypes f16x8 / f16x8c: the experts' cross terms as block-scaled FP6 e2m3 (6, the default: half the matrix-pipe time of "
                         "FP8 for ~1.15x its residual, bounded by the same conditioning guard) or FP8 e4m3 (8)")
     p.add_argument("--x8_layers", type=int, default=None,
-                   help="dtypes f16x8 / f16x8c: which expert tap layers at 8^3 take their cross terms through FP8 (bit 0 / 1 = inception1 "
+                   help="dtypes f16x8 / f16x8c: which expert tap layers at 8^3 take their cross terms through the narrow format (bit 0 / 1 = inception1 "
                         "conv2 (3^3) / conv3 (5^3), bit 2 / 3 = inception2 conv2 / conv3).  Default 15 = all four (outputs of small norm are "
                         "re-evaluated in f16x3 by the conditioning guard: 1 - cos <= 1.1e-6 against f16x3 on every other query); 10 = the "
                         "5^3 layers only (~2 %% slower); 0 = f16x3c proper")
@@ -124,7 +124,7 @@ def main(argv=None):
     from .config import CASCADE_DTYPES
     dtype = FLAGS.dtype if FLAGS.dtype != "auto" else (("f16x8c" if cfg.n_gaussians == 8 else "f16x3c") if arch == ARCH_EXPERTS else "f16x3")
     if dtype in CASCADE_DTYPES + ("f16x8",) and arch != ARCH_EXPERTS:
-        raise SystemExit("--dtype %s belongs to experts_n_est (two-stage gate / FP8 cross terms in the expert towers); use f16x3 for "
+        raise SystemExit("--dtype %s belongs to experts_n_est (two-stage gate / narrow-format cross terms in the expert towers); use f16x3 for "
                          "--model %s" % (dtype, FLAGS.model))
     if dtype in ("f16x8", "f16x8c") and cfg.n_gaussians != 8:
         raise SystemExit("--dtype %s needs the 8^3 Gaussian grid; use f16x3c" % dtype)
@@ -160,10 +160,10 @@ def main(argv=None):
             printout("gate margin for %s: tau = %.4g" % (name, calibrate_gate_margin(est.net, sp, sn)))
             del sp, sn
         if dtype in ("f16x8", "f16x8c"):
-            # the conditioning guard of the FP8 cross-term layers: its |n| threshold from the same sample of THIS shape
+            # the conditioning guard of the FP6 / FP8 cross-term layers: its |n| threshold from the same sample of THIS shape
             from .calibrate import calibrate_x8_guard
             sp, sn = cloud.build(0, min(1024, cloud.patch_count))
-            printout("FP8 guard threshold for %s: |n| < %.4g" % (name, calibrate_x8_guard(est.net, sp, sn)))
+            printout("cross-term guard threshold for %s: |n| < %.4g" % (name, calibrate_x8_guard(est.net, sp, sn)))
             del sp, sn
         normals, expert, probs = est.run(cloud)
         torch.cuda.synchronize()
@@ -185,10 +185,10 @@ def main(argv=None):
                          "%d more queries with the f16x3 gate before these files were written" % st["widened"])
         if dtype in ("f16x8", "f16x8c"):
             gs = est.net.x8_guard_stats()
-            printout("FP8 cross terms on %s: %d of %d expert outputs re-evaluated in f16x3 (|n| below %.4g), largest |dn| measured %.3g"
+            printout("narrow-format cross terms on %s: %d of %d expert outputs re-evaluated in f16x3 (|n| below %.4g), largest |dn| measured %.3g"
                      % (name, gs["rechecked"], gs["queries"], gs["thr_eff"], gs["max_dn"]))
             if gs["dropped"]:
-                printout("  WARNING: %d flagged outputs did not fit the guard's lists and keep their FP8-cross-term values: the "
+                printout("  WARNING: %d flagged outputs did not fit the guard's lists and keep their narrow-format cross-term values: the "
                          "1 - cos <= 2.5e-6 bound against f16x3 is not established for them (use --dtype f16x3c for this shape)" % gs["dropped"])
     flog.close()
     return 0

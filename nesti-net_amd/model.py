@@ -18,7 +18,7 @@ from .config import ARCH_MULTI, ARCH_SINGLE, CASCADE_DTYPES, DTYPES, NestiConfig
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16,
              "bf16x3": torch.bfloat16, "f16x3": torch.float16,   # pair modes: 16-bit elements, two planes [hi | lo] per 64-channel group
              "f16x3c": torch.float16,                            # f16x3 with the two-stage gate (include/nesti_hip.h: NESTI_F16X3C)
-             "f16x8": torch.float16, "f16x8c": torch.float16}    # f16x3 / f16x3c with the cross terms of the experts' tap layers at 8^3 through FP8 (NESTI_F16X8[C])
+             "f16x8": torch.float16, "f16x8c": torch.float16}    # f16x3 / f16x3c with the cross terms of the experts' tap layers at 8^3 through FP6 / FP8 (NESTI_F16X8[C])
 
 
 def get_3d_grid_gmm(subdivisions=(8, 8, 8), variance=0.0156):
@@ -73,7 +73,7 @@ class NestiNet:
     cosine tolerance of the f32 mode, bf16x3 is at its edge).  'f16x3c' is f16x3 with the two-stage gate: the gating net
     runs in plain f16 first and only the queries whose f16 top-2 logit margin is below ``gate_margin`` are decided by the
     f16x3 gating net (:meth:`set_gate_margin`, :meth:`cascade_stats`).  'f16x8' / 'f16x8c' are f16x3 / f16x3c with the two cross
-    terms of the experts' tap layers at 8^3 computed by one FP8 MFMA (include/nesti_hip.h: NESTI_F16X8; :meth:`set_x8_layers`)."""
+    terms of the experts' tap layers at 8^3 computed by one block-scaled FP6 (or FP8) MFMA (include/nesti_hip.h: NESTI_F16X8; :meth:`set_x8_layers`, :meth:`set_x8_format`)."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", max_batch=1024):
         self.lib = _lib.load()
@@ -131,7 +131,7 @@ class NestiNet:
                 "widened": int(st.widened), "widen_events": int(st.widen_events), "tau_eff": float(st.tau_eff)}
 
     def set_x8_layers(self, mask):
-        """dtype 'f16x8' / 'f16x8c': which expert tap layers at 8^3 take their cross terms through FP8 (``nesti_model_set_x8_layers``:
+        """dtype 'f16x8' / 'f16x8c': which expert tap layers at 8^3 take their cross terms through the narrow format (``nesti_model_set_x8_layers``:
         bit 0 / 1 = inception1 conv2 / conv3, bit 2 / 3 = inception2 conv2 / conv3; default 0b1111; 0 = f16x3 proper)."""
         _lib.check(self.lib.nesti_model_set_x8_layers(self._handle, int(mask)), "nesti_model_set_x8_layers")
 
