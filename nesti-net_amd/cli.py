@@ -144,9 +144,7 @@ def main(argv=None):
     if (FLAGS.x8_layers is not None or FLAGS.x8_format is not None) and dtype not in ("f16x8", "f16x8c"):
         raise SystemExit("--x8_layers / --x8_format belong to --dtype f16x8 / f16x8c")
     est = NormalEstimator(cfg, W, dtype=dtype, device=device, batch=batch, n_streams=2, subsample=FLAGS.subsample,
-                          x8_layers=FLAGS.x8_layers)
-    if FLAGS.x8_format is not None:
-        est.net.set_x8_format(FLAGS.x8_format)          # before the guard is calibrated per shape below
+                          x8_layers=FLAGS.x8_layers, x8_format=FLAGS.x8_format)
     printout("Model restored.")
 
     for ind, name in enumerate(dataset.shape_names):

@@ -19,7 +19,7 @@ class NormalEstimator:
     hipGraph once and replays it; only worthwhile for small batches where launch gaps matter."""
 
     def __init__(self, cfg: NestiConfig, weights, dtype="bf16", device="cuda:0", batch=4096, seed=3627473,
-                 use_graph=False, n_streams=1, gate_margin=None, subsample="hash", x8_layers=None):
+                 use_graph=False, n_streams=1, gate_margin=None, subsample="hash", x8_layers=None, x8_format=None):
         self.cfg, self.device, self.batch, self.seed = cfg, torch.device(device), int(batch), seed
         # subsample='reference': balls larger than P are thinned exactly like the reference does (scipy cKDTree traversal
         # order + ONE numpy RandomState stream over all patches in visiting order, utils/pcpnet_dataset.py:304-321), on the
@@ -52,6 +52,8 @@ class NormalEstimator:
             self.net.set_gate_margin(gate_margin)
         if x8_layers is not None:                         # dtypes 'f16x8' / 'f16x8c' only (NestiNet.set_x8_layers; default 0b1111)
             self.net.set_x8_layers(x8_layers)
+        if x8_format is not None:                         # ... and in which format (NestiNet.set_x8_format: 6 = block-scaled e2m3, the default; 8 = e4m3)
+            self.net.set_x8_format(x8_format)
         S, P, E = cfg.n_scales, cfg.num_point, max(1, cfg.n_gate_out)
         self._graph = None
         if self._fused:
