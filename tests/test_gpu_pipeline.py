@@ -91,7 +91,7 @@ def test_cli_default_mode_calibrates_the_gate_per_shape(dataset_dir, tmp_path, g
     """--dtype auto = f16x8c for experts_n_est on the 8^3 grid: the gate margin is calibrated on every shape (its counters are that
     shape's, printed to log.txt), two library batches are in flight on two streams, .experts equal the f16x3 mode's and .normals
     equal the f16x8 mode's bit for bit (the cascade is orthogonal to the expert arithmetic; same guard threshold) and stay within
-    2.5e-6 cosine of f16x3's (the FP8 cross terms of the experts' tap layers at 8^3 behind the conditioning guard, tests/test_gpu_x8.py)."""
+    2.5e-6 cosine of f16x3's (the FP6 cross terms of the experts' tap layers at 8^3 behind the conditioning guard, tests/test_gpu_x8.py)."""
     from nesti_net_amd import weights
     from nesti_net_amd.cli import main
     from nesti_net_amd.config import NestiConfig
@@ -126,6 +126,18 @@ def test_cli_default_mode_calibrates_the_gate_per_shape(dataset_dir, tmp_path, g
         cos = (n2.astype(np.float64) * normals).sum(1) / (np.linalg.norm(n2.astype(np.float64), axis=1) * np.linalg.norm(normals, axis=1))
         assert (1 - cos).max() <= 2.5e-6
         assert np.abs(p2 - probs).max() < 0.05
+    # --x8_format 8: the same files with the cross terms in FP8 e4m3 -- identical .experts, .normals within the same bar but not the same bits
+    results8 = str(tmp_path / "log8") + os.sep
+    os.makedirs(results8)
+    weights.save(os.path.join(results8, "model.nstw"), W, cfg)
+    assert main(["--results_path", results8, "--dataset_name", "synth", "--dataset_path", dataset_dir, "--testset", "testset.txt", "--x8_format", "8"]) == 0
+    a = np.loadtxt(os.path.join(out, "shapeA.normals"))
+    b = np.loadtxt(os.path.join(results8, "synth_results", "shapeA.normals"))
+    assert np.array_equal(np.loadtxt(os.path.join(out, "shapeA.experts")), np.loadtxt(os.path.join(results8, "synth_results", "shapeA.experts")))
+    cos = (a * b).sum(1) / (np.linalg.norm(a, axis=1) * np.linalg.norm(b, axis=1))
+    assert 0 < (1 - cos).max() <= 5e-6 and not np.array_equal(a, b)
+    with pytest.raises(SystemExit):
+        main(["--results_path", results8, "--dataset_name", "synth", "--dataset_path", dataset_dir, "--testset", "testset.txt", "--dtype", "f16x3", "--x8_format", "6"])
 
 
 def test_hipgraph_replay_matches_eager(gpu_device):
