@@ -19,6 +19,9 @@
 #ifndef NESTI_GUARD_WALK_GRID     // measurement builds may override it (scripts/ab_guard.sh); 1 = the default walking grid (kWalkGrid)
 #define NESTI_GUARD_WALK_GRID 64
 #endif
+#ifndef NESTI_GUARD_LANES         // auxiliary streams of the conditioning guard, one per caller stream (measurement builds: 1)
+#define NESTI_GUARD_LANES 2
+#endif
 #ifndef NESTI_GATE_WIDEN_WALK_GRID    // the two-stage gate's widening passes hold at most a few hundred rows (normally none)
 #define NESTI_GATE_WIDEN_WALK_GRID 1
 #endif
@@ -501,9 +504,24 @@ struct nesti_model {
   // e's guard runs on ONE auxiliary stream while the caller's stream goes on with expert e + 1 (events in both directions).  One
   // stream, not E: with more streams than hardware queues (4 by default) the event waits of one stream block the kernels of another
   // that shares its queue -- measured: E side streams cost the two-stream mode 3 %
-  mutable hipStream_t gstream = nullptr;
-  mutable hipEvent_t gev_done[NESTI_MAX_EXPERTS] = {}, gev_join = nullptr;
-  mutable std::mutex gmu;
+  // kGuardLanes such sets, keyed by the caller's stream (two library batches in flight on two streams -- the way the command line runs --
+  // get an auxiliary stream each: 2 + 2 = the 4 hardware queues; a third caller stream shares lane 0)
+  static constexpr int kGuardLanes = NESTI_GUARD_LANES;
+  struct GuardLane {
+    hipStream_t gstream = nullptr;
+    hipEvent_t gev_done[NESTI_MAX_EXPERTS] = {}, gev_join = nullptr;
+    hipStream_t owner = nullptr;
+    bool owned = false;
+    std::mutex gmu;
+  };
+  mutable GuardLane glane[kGuardLanes];
+  mutable std::mutex glane_mu;
+  GuardLane* guard_lane(hipStream_t caller) const {
+    std::lock_guard<std::mutex> lk(glane_mu);
+    for (int i = 0; i < kGuardLanes; ++i) if (glane[i].owned && glane[i].owner == caller) return &glane[i];
+    for (int i = 0; i < kGuardLanes; ++i) if (!glane[i].owned) { glane[i].owned = true; glane[i].owner = caller; return &glane[i]; }
+    return &glane[0];
+  }
   int gate_mix = 0;          // EXPERIMENT (nesti_model_set_gate_mix): the f16x3 gating passes run their tap layers single-product
   float tau = 0.25f;
   unsigned long long* cstat = nullptr;
@@ -515,9 +533,11 @@ struct nesti_model {
       }
     if (cstat) (void)hipFree(cstat);
     if (gstat) (void)hipFree(gstat);
-    if (gstream) (void)hipStreamDestroy(gstream);
-    for (auto& ev : gev_done) if (ev) (void)hipEventDestroy(ev);
-    if (gev_join) (void)hipEventDestroy(gev_join);
+    for (auto& gl : glane) {
+      if (gl.gstream) (void)hipStreamDestroy(gl.gstream);
+      for (auto& ev : gl.gev_done) if (ev) (void)hipEventDestroy(ev);
+      if (gl.gev_join) (void)hipEventDestroy(gl.gev_join);
+    }
   }
 };
 
@@ -1238,9 +1258,10 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
   }
   // (a stream that is being captured into a hipGraph keeps everything on itself: the guard then runs on the caller's stream, one
   // tower after the other, like it does when the two workspace slices do not fit)
-  const bool side = guard && m->gstream && main_bytes + guard_bytes <= tower_bytes_ && !prof_capturing(stream);
-  std::unique_lock<std::mutex> glk(m->gmu, std::defer_lock);
-  if (side) glk.lock();                        // the auxiliary stream and the events are the model's: one call enqueues on them at a time
+  nesti_model::GuardLane* lane = guard ? m->guard_lane(stream) : nullptr;
+  const bool side = guard && lane->gstream && main_bytes + guard_bytes <= tower_bytes_ && !prof_capturing(stream);
+  std::unique_lock<std::mutex> glk;
+  if (side) glk = std::unique_lock<std::mutex>(lane->gmu);   // the lane's auxiliary stream and events: one call enqueues on them at a time
   auto guard_expert = [&](int e, hipStream_t st, unsigned char* arena, size_t arena_bytes, int walk_grid) -> int {
     const Tower& T = m->graph.experts[e];
     int32_t* gl = glist + (size_t)e * gcap;
@@ -1276,9 +1297,9 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
     if (guard) {
       prof_phase(NESTI_PHASE_GUARD);
       if (side) {
-        NESTI_CHECK_HIP(hipEventRecord(m->gev_done[e], stream));
-        NESTI_CHECK_HIP(hipStreamWaitEvent(m->gstream, m->gev_done[e], 0));
-        if (guard_expert(e, m->gstream, tower_ws + main_bytes, tower_bytes_ - main_bytes, m->x8_guard_walk)) return 1;
+        NESTI_CHECK_HIP(hipEventRecord(lane->gev_done[e], stream));
+        NESTI_CHECK_HIP(hipStreamWaitEvent(lane->gstream, lane->gev_done[e], 0));
+        if (guard_expert(e, lane->gstream, tower_ws + main_bytes, tower_bytes_ - main_bytes, m->x8_guard_walk)) return 1;
       } else if (guard_expert(e, stream, tower_ws, tower_bytes_, m->x8_guard_walk)) {
         return 1;
       }
@@ -1287,8 +1308,8 @@ int experts_impl(const nesti_model* m, const void* X0, int B, int NB, unsigned c
   }
   if (guard) {
     if (side) {
-      NESTI_CHECK_HIP(hipEventRecord(m->gev_join, m->gstream));
-      NESTI_CHECK_HIP(hipStreamWaitEvent(stream, m->gev_join, 0));
+      NESTI_CHECK_HIP(hipEventRecord(lane->gev_join, lane->gstream));
+      NESTI_CHECK_HIP(hipStreamWaitEvent(stream, lane->gev_join, 0));
       glk.unlock();
     }
     prof_phase(NESTI_PHASE_GUARD);
@@ -1456,9 +1477,11 @@ int nesti_model_create(const nesti_config_t* cfg, const nesti_tensor_t* tensors,
     m->x8_mask = 0xF;          // all four tap layers at 8^3 (include/nesti_hip.h: nesti_model_set_x8_layers)
     NESTI_CHECK_HIP(hipMalloc((void**)&m->gstat, 64));
     NESTI_CHECK_HIP(hipMemset(m->gstat, 0, 64));
-    NESTI_CHECK_HIP(hipStreamCreateWithFlags(&m->gstream, hipStreamNonBlocking));
-    NESTI_CHECK_HIP(hipEventCreateWithFlags(&m->gev_join, hipEventDisableTiming));
-    for (int e = 0; e < cfg->n_experts; ++e) NESTI_CHECK_HIP(hipEventCreateWithFlags(&m->gev_done[e], hipEventDisableTiming));
+    for (auto& gl : m->glane) {
+      NESTI_CHECK_HIP(hipStreamCreateWithFlags(&gl.gstream, hipStreamNonBlocking));
+      NESTI_CHECK_HIP(hipEventCreateWithFlags(&gl.gev_join, hipEventDisableTiming));
+      for (int e = 0; e < cfg->n_experts; ++e) NESTI_CHECK_HIP(hipEventCreateWithFlags(&gl.gev_done[e], hipEventDisableTiming));
+    }
   }
   if (m->cascade) {
     m->packed_fast.resize(m->graph.layers.size());
