@@ -400,6 +400,11 @@ int nesti_write_text_i32(const char* path, const int32_t* data, int64_t rows);
  * restore (test_n_est_w_experts.py:98-105 -> tf_ckpt.read_bundle).  Stored masked: ((crc >> 15) | (crc << 17)) + 0xa282ead8. */
 uint32_t nesti_crc32c(const void* data, size_t n, uint32_t crc);
 
+/* The OCP FP6 e2m3 code (sign bit 5, exponent bits 4-3 with bias 1, mantissa bits 2-0; grid 0, 0.125 .. 7.5) of value * inv_scale, rounded to
+ * nearest even and saturating -- the host-side encoder of the FP6 weight packing (nesti_model_set_x8_format), exposed so that it can be
+ * checked against the instruction's own decoding without a device (tests/test_abi.py; scripts/fp6_probe.hip holds the device side). */
+int nesti_f32_to_e2m3(float value, float inv_scale);
+
 /* ---- measurement support (bench.py's roofline leg; no reference counterpart) ------------
  * nesti_profile_enable(1) makes every kernel launch of the forward path record a pair of
  * hipEvents on its stream; nesti_profile_read() synchronises on them and returns, per

@@ -96,6 +96,7 @@ SIGNATURES = {
     "nesti_estimate_normals": (_i, [_vp, _vp, _i, _vp, _i, ctypes.POINTER(ctypes.c_double), _u64, _i, _i, _i, _vp, _sz,
                                     _vp, _sz, _vp, _vp, _vp, _vp]),
     "nesti_crc32c": (ctypes.c_uint32, [_vp, _sz, ctypes.c_uint32]),
+    "nesti_f32_to_e2m3": (_i, [ctypes.c_float, ctypes.c_float]),
     "nesti_write_text_f32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64, _i]),
     "nesti_write_text_i32": (_i, [ctypes.c_char_p, _vp, ctypes.c_int64]),
     "nesti_estimate_normals_multi": (_i, [_vp, ctypes.POINTER(CShapeQueries), _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),

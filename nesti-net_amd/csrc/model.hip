@@ -1530,6 +1530,8 @@ int nesti_model_set_x8_layers(nesti_model_t* m, int mask) {
   return 0;
 }
 
+int nesti_f32_to_e2m3(float value, float inv_scale) { return (int)host_f32_to_e2m3(value, inv_scale); }
+
 int nesti_model_set_x8_format(nesti_model_t* m, int bits) {
   if (!m) NESTI_FAIL("nesti_model_set_x8_format: null model");
   if (m->packed_x8.empty()) NESTI_FAIL("nesti_model_set_x8_format: not an NESTI_F16X8 / NESTI_F16X8C model");

@@ -209,3 +209,33 @@ def test_x8_dtypes_are_refused_where_they_do_not_apply():
             msg = lib.nesti_last_error().decode()
             assert "F16X8" in msg or "two-stage gate" in msg, msg
     assert lib.nesti_model_set_x8_layers(None, 0xF) != 0 and lib.nesti_model_set_x8_guard(None, ctypes.c_float(0.1)) != 0
+
+
+def test_e2m3_encoder_rounds_to_nearest_even_and_saturates():
+    """The host-side FP6 encoder of the weight packing (model.hip: host_f32_to_e2m3) against the format's definition: every code decodes and
+    encodes back to itself, a value between two grid points goes to the nearer one, an exact midpoint to the even mantissa, everything
+    beyond 7.5 saturates, the sign rides in bit 5, the scale divides."""
+    from nesti_net_amd import _lib
+    lib = _lib.load()
+
+    def dec(c):
+        e, m = (c >> 3) & 3, c & 7
+        v = m * 0.125 if e == 0 else (1 + m * 0.125) * 2.0 ** (e - 1)
+        return -v if c & 32 else v
+
+    grid = [dec(c) for c in range(32)]
+    assert grid == sorted(grid) and grid[31] == 7.5 and grid[1] == 0.125
+    for c in range(64):
+        if c == 32:
+            continue                                        # -0 encodes as the sign bit alone: checked below
+        assert lib.nesti_f32_to_e2m3(dec(c), 1.0) == c
+    assert lib.nesti_f32_to_e2m3(-0.0, 1.0) in (0, 32)
+    for c in range(31):
+        lo, hi = grid[c], grid[c + 1]
+        assert lib.nesti_f32_to_e2m3(lo + 0.25 * (hi - lo), 1.0) == c and lib.nesti_f32_to_e2m3(lo + 0.75 * (hi - lo), 1.0) == c + 1
+        assert lib.nesti_f32_to_e2m3(0.5 * (lo + hi), 1.0) == (c if c % 2 == 0 else c + 1)       # ties to the even mantissa
+        assert lib.nesti_f32_to_e2m3(-0.5 * (lo + hi), 1.0) == 32 + (c if c % 2 == 0 else c + 1)
+    for v in (7.6, 7.75, 8.0, 100.0, 1e30, float("inf")):
+        assert lib.nesti_f32_to_e2m3(v, 1.0) == 31 and lib.nesti_f32_to_e2m3(-v, 1.0) == 63
+    assert lib.nesti_f32_to_e2m3(0.06, 1.0) == 0 and lib.nesti_f32_to_e2m3(0.0626, 1.0) == 1     # the probe's cases (profiles/r06_fp6_probe.txt)
+    assert lib.nesti_f32_to_e2m3(24.0, 0.25) == lib.nesti_f32_to_e2m3(6.0, 1.0) == 28
